@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF.
+
+Runs ONLY in the build container (needs /root/reference); the .npz files it writes are the
+committed fixtures, this script is the committed recipe.  Nothing of the reference's source
+is stored: the script reads the text of
+    /root/reference/extensions/mvpraymarch/mvpraymarch.py
+at run time, redirects "cuda" -> "cpu", shrinks the hard-coded scene constants of `gradcheck`
+(N/H/W/k3/M, mvpraymarch.py:434-440) so that the fixtures stay small, switches the default
+dtype to float64 and executes the reference's dense PyTorch statement of the raymarch
+(mvpraymarch.py:553-633) plus its autograd backward (:633-641).  A stand-in for the CUDA entry
+point `mvpraymarch` captures (a) exactly the tensors the CUDA path would have received and
+(b) the dense result `sample0` / `grads0` from the caller's frame.
+
+Also writes raydirs goldens from the reference's dense ray-generation statement
+(extensions/utils/utils.py:130-148) in float64.
+
+Usage:  python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Captured(Exception):
+    pass
+
+
+def run_reference_gradcheck(N, H, W, k3, M, fadescale, fadeexp, alpha_shift=None):
+    torch.set_default_dtype(torch.float64)
+    sys.modules["mvpraymarchlib"] = types.ModuleType("mvpraymarchlib")  # CUDA module stand-in
+    src = open(os.path.join(REF, "extensions/mvpraymarch/mvpraymarch.py")).read()
+    rep = [
+        ('"cuda"', '"cpu"'),
+        ("torch.cuda.synchronize()", "pass"),
+        ("from . import mvpraymarchlib", "import mvpraymarchlib"),
+        ("    N = 2\n", "    N = %d\n" % N),
+        ("    H = 65\n", "    H = %d\n" % H),
+        ("    W = 65\n", "    W = %d\n" % W),
+        ("    k3 = 4\n", "    k3 = %d\n" % k3),
+        ("    M = 32\n", "    M = %d\n" % M),
+    ]
+    if alpha_shift is not None:  # opacity offset of the random template (mvpraymarch.py:494)
+        rep.append(("_template.data[:, :, -1, :, :, :] -= 3.5", "_template.data[:, :, -1, :, :, :] -= %r" % alpha_shift))
+    for a, b in rep:
+        assert a in src, a
+        src = src.replace(a, b)
+    ns = {"__name__": "refmvp"}
+    exec(compile(src, "refmvp", "exec"), ns)
+    cap = {}
+
+    def capture(raypos, raydir, stepsize, tminmax, primtransf, template, warp, **kw):
+        f = sys._getframe(1).f_locals
+        cap["args"] = dict(raypos=raypos, raydir=raydir, stepsize=stepsize, tminmax=tminmax,
+                           primpos=primtransf[0], primrot=primtransf[1], primscale=primtransf[2],
+                           template=template, kw=kw)
+        cap["sample0"] = f["sample0"]
+        cap["grads0"] = dict(zip(f["paramnames"], f["grads0"]))
+        cap["raw"] = dict(_template=f["_template"], _primscale=f["_primscale"])
+        raise _Captured()
+
+    ns["mvpraymarch"] = capture
+    t0 = time.time()
+    try:
+        ns["gradcheck"](usebvh="fixedorder", sortprims=False, maxhitboxes=512, synchitboxes=True, dowarp=False,
+                        chlast=True, fadescale=fadescale, fadeexp=fadeexp, accum=0, algo=0, griddim=3)
+    except _Captured:
+        pass
+    cap["seconds"] = time.time() - t0
+    torch.set_default_dtype(torch.float32)
+    return cap
+
+
+def save_march(name, **cfg):
+    cap = run_reference_gradcheck(**cfg)
+    a = cap["args"]
+    tpl_raw = cap["raw"]["_template"].detach()  # [N,K,4,M,M,M]
+    # chain factors from the inputs handed to the raymarcher back to gradcheck's raw leaves:
+    # template = softplus(1.5*_template) (mvpraymarch.py:561), primpos = 0.3*_primpos (:563),
+    # primscale = exp(0.1*_primscale) (:565), primrot identity (:564).
+    chain_template = (1.5 * torch.sigmoid(1.5 * tpl_raw)).permute(0, 1, 3, 4, 5, 2).contiguous()
+    out = dict(
+        raypos=a["raypos"], raydir=a["raydir"], tminmax=a["tminmax"], stepsize=np.float64(a["stepsize"]),
+        primpos=a["primpos"], primrot=a["primrot"], primscale=a["primscale"], template=a["template"],
+        fadescale=np.float64(cfg["fadescale"]), fadeexp=np.float64(cfg["fadeexp"]),
+        rgba=cap["sample0"],
+        graw_template=cap["grads0"]["template"].permute(0, 1, 3, 4, 5, 2).contiguous(),
+        graw_primpos=cap["grads0"]["primpos"], graw_primrot=cap["grads0"]["primrot"],
+        graw_primscale=cap["grads0"]["primscale"],
+        chain_template=chain_template, chain_primpos=np.float64(0.3), chain_primscale=0.1 * a["primscale"],
+    )
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+    for k, v in out.items():
+        assert v.dtype in (np.float64,), (k, v.dtype)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    rg = out["rgba"]
+    print("%s: %.1fs reference dense loop on CPU; rgba alpha in [%.3f, %.3f], saturated %.0f%%, %d KB" % (
+        name, cap["seconds"], rg[..., 3].min(), rg[..., 3].max(), 100 * (rg[..., 3] >= 1 - 1e-9).mean(),
+        os.path.getsize(path) // 1024))
+
+
+def save_raydirs(name, N=2, H=12, W=20, volradius=1.0):
+    """Dense ray generation exactly as extensions/utils/utils.py:130-148 states it (float64)."""
+    torch.set_default_dtype(torch.float64)
+    sys.modules["utilslib"] = types.ModuleType("utilslib")
+    src = open(os.path.join(REF, "extensions/utils/utils.py")).read()
+    src = src.replace("from . import utilslib", "import utilslib")
+    ns = {"__name__": "refutils"}
+    exec(compile(src, "refutils", "exec"), ns)
+    torch.manual_seed(1113)  # utils.py:94
+    rodrigues = ns["Rodrigues"]()
+    viewpos = torch.tensor([[-0.0, 0.0, -4.0] for n in range(N)]) + torch.randn(N, 3) * 0.1
+    viewrot = rodrigues(torch.randn(N, 3) * 0.01)
+    focal = torch.tensor([[W * 4.0, W * 4.1] for n in range(N)])
+    princpt = torch.tensor([[W * 0.5, H * 0.45] for n in range(N)])
+    pixely, pixelx = torch.meshgrid(torch.arange(H).double(), torch.arange(W).double(), indexing="ij")
+    pixelcoords = torch.stack([pixelx, pixely], dim=-1)[None].repeat(N, 1, 1, 1) + 0.25
+    # --- the reference's dense statement, utils.py:130-148 (volradius == 1 there) ---
+    raypos = viewpos[:, None, None, :].repeat(1, H, W, 1)
+    raydir = (pixelcoords - princpt[:, None, None, :]) / focal[:, None, None, :]
+    raydir = torch.cat([raydir, torch.ones_like(raydir[:, :, :, 0:1])], dim=-1)
+    raydir = torch.sum(viewrot[:, None, None, :, :] * raydir[:, :, :, :, None], dim=-2)
+    raydir = raydir / torch.sqrt(torch.sum(raydir ** 2, dim=-1, keepdim=True))
+    t1 = (-1.0 - viewpos[:, None, None, :]) / raydir
+    t2 = (1.0 - viewpos[:, None, None, :]) / raydir
+    tmin = torch.max(torch.min(t1[..., 0], t2[..., 0]),
+                     torch.max(torch.min(t1[..., 1], t2[..., 1]), torch.min(t1[..., 2], t2[..., 2]))).clamp(min=0.0)
+    tmax = torch.min(torch.max(t1[..., 0], t2[..., 0]),
+                     torch.min(torch.max(t1[..., 1], t2[..., 1]), torch.max(t1[..., 2], t2[..., 2])))
+    tminmax = torch.stack([tmin, tmax], dim=-1)
+    torch.set_default_dtype(torch.float32)
+    out = dict(viewpos=viewpos, viewrot=viewrot, focal=focal, princpt=princpt, pixelcoords=pixelcoords,
+               volradius=np.float64(volradius), raypos=raypos, raydir=raydir, tminmax=tminmax)
+    out = {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "written")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    # reference __main__ settings (mvpraymarch.py:749-761): fadescale 6.5, fadeexp 7.5
+    save_march("march_k8_m8", N=2, H=17, W=17, k3=2, M=8, fadescale=6.5, fadeexp=7.5)
+    # production fade (mvpraymarch.py:311-312 defaults), K=64, small slabs
+    save_march("march_k64_m4", N=2, H=13, W=13, k3=4, M=4, fadescale=8.0, fadeexp=8.0)
+    # dense opacity: most rays saturate -> exercises the raysat backward rule (primaccum.h:86-93)
+    save_march("march_k8_m8_sat", N=1, H=15, W=15, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0)
+    save_raydirs("raydirs_small")
