@@ -1,0 +1,20 @@
+"""ava-256_amd -- MI355X-native (gfx950 / CDNA4) MVP-raymarch hot path behind ava-256's operator API.
+
+Only what the path needs lives here:
+  csrc/            hand-written HIP kernels + the C-ABI (include/mvp_abi.h) -> libmvp_gfx950.so
+  build.py         hipcc driver (in-tree build, no torch extension machinery)
+  _lib.py          ctypes binding of the C-ABI (fails loudly when the library is missing)
+  raydirs.py       compute_raydirs / ComputeRaydirs          (reference: extensions/utils/utils.py:21-51)
+  mvpraymarch.py   mvpraymarch / MVPRaymarch / build_accel   (reference: extensions/mvpraymarch/mvpraymarch.py:21-390)
+  raymarcher.py    Raymarcher nn.Module                      (reference: models/raymarchers/mvpraymarcher.py:17-54)
+  scene.py         seeded synthetic scenes for tests and bench
+
+The directory name contains a hyphen (it is the name the build contract asks for); import it as
+``ava256_amd`` (a two-line alias package next to it).  There is NO CPU fallback: every operator raises
+if its tensors are not on a HIP device or if libmvp_gfx950.so has not been built.
+"""
+from .raydirs import ComputeRaydirs, compute_raydirs  # noqa: F401
+from .mvpraymarch import MVPRaymarch, build_accel, mvpraymarch  # noqa: F401
+from .raymarcher import Raymarcher  # noqa: F401
+
+__all__ = ["compute_raydirs", "ComputeRaydirs", "mvpraymarch", "MVPRaymarch", "build_accel", "Raymarcher"]

@@ -1,0 +1,54 @@
+"""ctypes binding of the C ABI declared in include/mvp_abi.h (libmvp_gfx950.so).
+
+No fallback of any kind: if the library is missing the first operator call raises, and every
+non-zero status returned by the library is turned into a RuntimeError.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvp_gfx950.so")
+
+_c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); one entry per declaration in include/mvp_abi.h
+SIGNATURES = {
+    "mvp_abi_version": (_c_int, []),
+    "mvp_error_string": (ctypes.c_char_p, [_c_int]),
+    "mvp_device_arch": (_c_int, [_c_int, ctypes.c_char_p, _c_int]),
+    "mvp_raydirs_forward": (_c_int, [_c_int] * 3 + [_c_void_p] * 5 + [_c_float] + [_c_void_p] * 3 + [_c_void_p]),
+    "mvp_aabb_build": (_c_int, [_c_int] * 2 + [_c_void_p] * 4 + [_c_void_p]),
+    "mvp_march_forward": (_c_int, [_c_int] * 4 + [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 5 + [_c_int] * 3 +
+                          [_c_void_p] * 3 + [_c_float] * 2 + [_c_void_p] * 2),
+    "mvp_march_backward": (_c_int, [_c_int] * 4 + [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 5 + [_c_int] * 3 +
+                           [_c_void_p] * 7 + [_c_float] * 2 + [_c_void_p] * 2),
+}
+ABI_VERSION = 1
+DIAG_WORDS = 8
+DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit"]
+
+_lib = None
+
+
+def get_lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmvp_gfx950.so is not built (%s). Build it with `python -c \"import __graft_entry__ as g; "
+                "g.build()\"` or `python ava-256_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.mvp_abi_version() != ABI_VERSION:
+            raise RuntimeError("libmvp_gfx950.so ABI version %d != expected %d (stale build?)" %
+                               (lib.mvp_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = get_lib().mvp_error_string(code)
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

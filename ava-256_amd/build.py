@@ -1,0 +1,50 @@
+"""In-tree hipcc build of libmvp_gfx950.so (gfx950 only; hipcc cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmvp_gfx950.so")
+SOURCES = ["raydirs.hip", "aabb.hip", "march.hip", "abi_misc.hip"]
+HEADERS = [os.path.join(CSRC, "mvp_device.h"), os.path.join(CSRC, "mvp_host.h"),
+           os.path.join(ROOT, "include", "mvp_abi.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (ROCm toolchain missing)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library next to this file. Returns its path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    if verbose and res.stdout.strip():
+        print(res.stdout)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

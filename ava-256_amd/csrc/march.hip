@@ -1,0 +1,645 @@
+// march.hip -- Mixture-of-Volumetric-Primitives raymarch, forward and backward, hand-written for gfx950 (CDNA4).
+//
+// WHAT it computes (bit-for-bit the same sample set and composition order as the reference):
+//   /root/reference/extensions/mvpraymarch/mvpraymarch_subset_kernel.h:7-100   (forward)
+//   /root/reference/extensions/mvpraymarch/mvpraymarch_subset_kernel.h:102-216 (backward, forwarddir=true)
+//   utils.h:719-815 (fixed-order BVH traversal, leaf test), primtransf.h:105-179 (SRT), primsampler.h:44-91 +
+//   utils.h:408-643 (fade + channels-last trilinear), primaccum.h:37-98 (additive accumulation, raysat rule).
+//   A ray's result is  sum over lattice steps t_s = tmin + s*dt (s >= floor((rtmin-tmin)/dt), t_s < rtmax+1e-5),
+//   over listed primitives in DFS-leaf order, of the samples whose box coordinate is strictly inside (-1,1)^3,
+//   composited front to back until alpha saturates.
+//
+// HOW it is organised here is NOT the reference's schedule (a warp walks the tree node by node, then every
+// step tests every listed primitive).  On CDNA4:
+//   * one wave64 = one 8x8 pixel packet (one workgroup = one wave, private LDS, no cross-wave barriers);
+//   * BVH traversal is breadth-first with LANES OVER NODES: each lane tests one frontier node's AABB against
+//     the packet's interval bounds (origin box x 1/dir box, conservative), survivors are compacted in
+//     left-to-right order with ballot + popcount prefix sums.  log2(K)-6 dependent memory round trips per
+//     packet instead of one per visited node;
+//   * candidates are then tested EXACTLY per ray (the reference's leaf test, utils.h:744-761) with LANES OVER
+//     RAYS, reading the 15-float SRT records staged once into LDS; this yields the per-ray march interval
+//     and, per listed primitive, a packet-level lattice-step range [lo,hi];
+//   * the march sweeps lattice steps and visits only (step, primitive) pairs whose range contains the step:
+//     a ballot over the ranges (lanes over list slots) gives the active-slot mask, empty stretches are
+//     skipped with one wave-min.  Positions are evaluated directly, x_s = o + d*(tmin + s*dt), instead of by
+//     ~150 accumulated fp32 adds (utils: subset_kernel.h:95-96), which is closer to the fp64 truth;
+//   * packets that miss everything exit after the first frontier round (ray compaction by ballot).
+//   * the inside-test guarantees all 8 trilinear corners are in bounds, so the sampler needs no bounds checks.
+//   * backward: template gradients are fp32 hardware atomics (global_atomic_add_f32); the 15 pose gradients
+//     of a (step, primitive) pair are reduced across the wave (12 sufficient sums) and flushed by 15 lanes.
+#include "mvp_device.h"
+#include "mvp_host.h"
+
+namespace mvp {
+
+constexpr int kTile = 8;          // 8x8 pixels per wave
+constexpr int kMaxList = 512;     // reference hit-list cap (mvpraymarch_kernel.cu:101, utils.h:779)
+constexpr int kRecSlots = 64;     // SRT records staged in LDS (first 64 candidates); beyond: scalar global loads
+constexpr int kStartDepth = 6;    // BFS starts with all 64 nodes of depth 6 (one per lane)
+constexpr int kNoSlot = 255;
+
+struct MarchParams {
+    int N, H, W, K;
+    int TD, TH, TW;
+    int tiles_x, tiles_y, chunk;  // 8x8 packets per image row / column; packets per (image, XCD) chunk
+    float stepsize, fadescale, fadeexp;
+    const float *raypos, *raydir, *tminmax, *nodeaabb, *primpos, *primrot, *primscale, *tplate;
+    float *rayrgba, *raysat;                     // forward outputs
+    const float *raysat_in, *grad_rayrgba;       // backward inputs
+    float *grad_primpos, *grad_primrot, *grad_primscale, *grad_tplate;
+    uint32_t *diag;
+};
+
+struct Rec {  // one primitive's transform, wave-uniform while it is being processed
+    f3 pos, r0, r1, r2, scale;
+};
+
+__device__ __forceinline__ Rec rec_from_lds(const float4 *s_rec, int slot) {
+    const float4 a = s_rec[slot * 4 + 0], b = s_rec[slot * 4 + 1], c = s_rec[slot * 4 + 2], d = s_rec[slot * 4 + 3];
+    Rec r;
+    r.pos = mk3(a.x, a.y, a.z);
+    r.r0 = mk3(a.w, b.x, b.y);
+    r.r1 = mk3(b.z, b.w, c.x);
+    r.r2 = mk3(c.y, c.z, c.w);
+    r.scale = mk3(d.x, d.y, d.z);
+    return r;
+}
+__device__ __forceinline__ Rec rec_from_global(const float *pp, const float *pr, const float *ps, int k) {
+    Rec r;
+    r.pos = ld3(pp + (size_t)k * 3);
+    r.r0 = ld3(pr + (size_t)k * 9);
+    r.r1 = ld3(pr + (size_t)k * 9 + 3);
+    r.r2 = ld3(pr + (size_t)k * 9 + 6);
+    r.scale = ld3(ps + (size_t)k * 3);
+    return r;
+}
+
+// primtransf.h:119-132: xmt = x - pos; rxmt = R0*xmt.x + R1*xmt.y + R2*xmt.z; y = rxmt * scale
+__device__ __forceinline__ f3 rot_rows(const Rec &r, f3 v) {
+    return mk3(r.r0.x * v.x + r.r1.x * v.y + r.r2.x * v.z, r.r0.y * v.x + r.r1.y * v.y + r.r2.y * v.z,
+               r.r0.z * v.x + r.r1.z * v.y + r.r2.z * v.z);
+}
+
+struct AxisBounds {  // wave-uniform interval description of one axis of the 64 rays
+    float olo, ohi;  // origin interval
+    float ilo, ihi;  // 1/dir interval
+    int sgn;         // +1: every active dir component > 0, -1: every one < 0, 0: mixed / zero
+};
+struct PacketBounds {  // conservative culling only
+    AxisBounds ax, ay, az;
+    float tlo, thi;  // [min tmin, max tmax + 1e-5]
+};
+
+__device__ __forceinline__ void axis_clip(const AxisBounds &a, float bmin, float bmax, float &tn, float &tf) {
+    if (a.sgn > 0) {
+        const float u = bmin - a.ohi;  // smallest (bmin - o)
+        const float v = bmax - a.olo;  // largest (bmax - o)
+        tn = fmaxf(tn, u * (u >= 0.f ? a.ilo : a.ihi));
+        tf = fminf(tf, v * (v >= 0.f ? a.ihi : a.ilo));
+    } else if (a.sgn < 0) {
+        const float u = bmax - a.olo;  // largest (bmax - o); 1/dir < 0
+        const float w = bmin - a.ohi;  // smallest (bmin - o)
+        tn = fmaxf(tn, u * (u >= 0.f ? a.ilo : a.ihi));
+        tf = fminf(tf, w * (w <= 0.f ? a.ilo : a.ihi));
+    }
+}
+
+// Conservative: returns true whenever ANY ray of the packet passes the reference's slab test
+// (utils.h:679-685) within the packet's t range; extra candidates are harmless (exact test follows).
+__device__ __forceinline__ bool packet_hits_box(const PacketBounds &pb, float x0, float y0, float z0, float x1,
+                                                float y1, float z1) {
+    float tn = pb.tlo, tf = pb.thi;
+    axis_clip(pb.ax, x0, x1, tn, tf);
+    axis_clip(pb.ay, y0, y1, tn, tf);
+    axis_clip(pb.az, z0, z1, tn, tf);
+    return tn <= tf + 1e-4f + 1e-5f * fabsf(tf);
+}
+
+__device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d) {
+    AxisBounds a;
+    a.olo = uni(wave_min(active ? o : INFINITY));
+    a.ohi = uni(wave_max(active ? o : -INFINITY));
+    const float ird = 1.0f / d;
+    a.ilo = uni(wave_min(active ? ird : INFINITY));
+    a.ihi = uni(wave_max(active ? ird : -INFINITY));
+    const bool allpos = __ballot(active && !(d > 0.f)) == 0ull;
+    const bool allneg = __ballot(active && !(d < 0.f)) == 0ull;
+    a.sgn = allpos ? 1 : (allneg ? -1 : 0);
+    return a;
+}
+
+template <bool BWD, bool FADE8>
+__global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
+    __shared__ int s_a[kMaxList];              // frontier ping; later packed step ranges (lo | hi << 16)
+    __shared__ int s_b[kMaxList];              // frontier pong / candidate list / final list (k | slot << 24)
+    __shared__ float4 s_rec[kRecSlots * 4];    // SRT records of the first 64 candidates (16 floats each)
+
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt(lane);
+
+    // ---- packet -> (image, tile): block b runs on XCD b % 8 (MI355X_MICROARCH "Workgroup dispatch"); give every
+    //      XCD a contiguous run of `chunk` row-major packets of each image so its private L2 sees a compact band.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, i = b >> 3;
+    const int n = i / p.chunk;
+    const int tidx = xcd * p.chunk + (i - n * p.chunk);
+    if (tidx >= p.tiles_x * p.tiles_y) return;
+    const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
+    const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+    const bool inimg = px < p.W && py < p.H;
+    const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
+
+    const int K = p.K, NN = 2 * K - 1;
+    const float dt = p.stepsize;
+    const float *pp = p.primpos + (size_t)n * K * 3;
+    const float *pr = p.primrot + (size_t)n * K * 9;
+    const float *ps = p.primscale + (size_t)n * K * 3;
+    const float *A = p.nodeaabb + (size_t)n * NN * 6;
+
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    float tmin = INFINITY, tmax = -INFINITY;
+    if (inimg) {
+        o = ld3(p.raypos + r * 3);
+        d = ld3(p.raydir + r * 3);
+        const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
+        tmin = tt.x;
+        tmax = tt.y;
+    }
+    // a ray can only take a sample at t in [tmin, tmax + 1e-5) (subset_kernel.h:63-64,84)
+    const bool active = inimg && (tmin < tmax + 1e-5f);
+
+    float4 rgba = make_float4(0.f, 0.f, 0.f, 0.f);
+    f3 raysat = mk3(-1.f, -1.f, -1.f);
+    int nh = 0;            // final list length (wave-uniform)
+    int ncand = 0;
+
+    if (__ballot(active) != 0ull) {
+        // ---------------- packet bounds (6-step butterflies, once per packet) ----------------
+        PacketBounds pb;
+        pb.ax = axis_bounds(active, o.x, d.x);
+        pb.ay = axis_bounds(active, o.y, d.y);
+        pb.az = axis_bounds(active, o.z, d.z);
+        pb.tlo = uni(wave_min(active ? tmin : INFINITY));
+        pb.thi = uni(wave_max(active ? tmax + 1e-5f : -INFINITY));
+
+        // ---------------- breadth-first frontier expansion, lanes over nodes ----------------
+        const int dmax = 31 - __clz(NN);  // depth of the deepest node; depth(i) = floor(log2(i+1))
+        // leaves sit at depth dmax or dmax-1: start no deeper than dmax-1 so that none is skipped
+        const int ds = max(0, min(dmax - 1, kStartDepth));
+        int *cur = s_a, *nxt = s_b;
+        int ncur;
+        {
+            const int first = (1 << ds) - 1;
+            ncur = min(1 << ds, NN - first);
+            if (lane < ncur) cur[lane] = first + lane;
+        }
+        __syncthreads();
+        bool frontier_ovf = false;
+        for (int dep = ds;; ++dep) {
+            int nnext = 0;
+            for (int base = 0; base < ncur; base += kWave) {
+                const int idx = base + lane;
+                const bool have = idx < ncur;
+                const int e = have ? cur[idx] : 0;
+                const bool tested_leaf = e < 0;  // ~node: a leaf that already passed, carried to keep order
+                const int g = tested_leaf ? ~e : e;
+                bool pass = have && tested_leaf;
+                if (have && !tested_leaf) {
+                    const float2 *ap = reinterpret_cast<const float2 *>(A + (size_t)g * 6);  // 24 B nodes: 8-B aligned
+                    const float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+                    pass = packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+                }
+                const bool isleaf = g >= K - 1;
+                const bool e1 = pass, e2 = pass && !isleaf;
+                const unsigned long long m1 = __ballot(e1), m2 = __ballot(e2);
+                const int pos = nnext + __popcll(m1 & lt) + __popcll(m2 & lt);
+                if (e1 && pos < kMaxList) nxt[pos] = isleaf ? ~g : 2 * g + 1;
+                if (e2 && pos + 1 < kMaxList) nxt[pos + 1] = 2 * g + 2;
+                nnext += __popcll(m1) + __popcll(m2);
+            }
+            if (nnext > kMaxList) {
+                frontier_ovf = true;
+                nnext = kMaxList;
+            }
+            __syncthreads();
+            int *t = cur;
+            cur = nxt;
+            nxt = t;
+            ncur = nnext;
+            if (ncur == 0 || dep >= dmax) break;
+        }
+        ncand = ncur;  // entries of `cur` are ~node of tested leaves, in DFS (left-to-right) order
+        if (frontier_ovf && p.diag && lane == 0) atomicAdd(p.diag + MVP_DIAG_FRONTIER_OVERFLOW, 1u);
+
+        // move candidates into s_b as primitive indices (cur may be either buffer)
+        if (ncand > 0) {
+            int kk[kMaxList / kWave];
+#pragma unroll
+            for (int c = 0; c < kMaxList / kWave; ++c) {
+                const int idx = c * kWave + lane;
+                kk[c] = idx < ncand ? (~cur[idx]) - (K - 1) : 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < kMaxList / kWave; ++c) {
+                const int idx = c * kWave + lane;
+                if (idx < ncand) s_b[idx] = kk[c];
+            }
+            // stage the SRT records of the first 64 candidates: lanes over candidates, one gather round trip
+            if (lane < ncand && lane < kRecSlots) {
+                const Rec q = rec_from_global(pp, pr, ps, kk[0]);
+                s_rec[lane * 4 + 0] = make_float4(q.pos.x, q.pos.y, q.pos.z, q.r0.x);
+                s_rec[lane * 4 + 1] = make_float4(q.r0.y, q.r0.z, q.r1.x, q.r1.y);
+                s_rec[lane * 4 + 2] = make_float4(q.r1.z, q.r2.x, q.r2.y, q.r2.z);
+                s_rec[lane * 4 + 3] = make_float4(q.scale.x, q.scale.y, q.scale.z, 0.f);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---------------- exact per-ray leaf test (utils.h:744-761), lanes over rays ----------------
+    float rtmin = INFINITY, rtmax = -INFINITY;
+    bool ranges_ok = true;  // false when a step index does not fit the packed 16-bit range
+    for (int c = 0; c < ncand; ++c) {
+        const int k = uni(s_b[c]);
+        const int slot = c < kRecSlots ? c : kNoSlot;
+        const Rec q = (c < kRecSlots) ? rec_from_lds(s_rec, c) : rec_from_global(pp, pr, ps, k);
+        const f3 r0 = rot_rows(q, o - q.pos) * q.scale;  // primtransf.h:134-153
+        const f3 rd = rot_rows(q, d) * q.scale;
+        const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
+        const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
+        const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+        const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+        const bool hit = active && (tn <= tf);
+        if (hit) {
+            rtmin = fminf(rtmin, tn);
+            rtmax = fmaxf(rtmax, tf);
+        }
+        // lattice steps of this ray that can fall inside this primitive (+-1 step of slack; the strict
+        // inside test on the evaluated position decides, exactly as in the reference)
+        const float ta = fmaxf(tn, tmin), tb = fminf(tf, tmax + 1e-5f);
+        const bool some = hit && (ta <= tb);
+        int lo = 0x7fffffff, hi = -1;
+        if (some) {
+            const float flo = floorf((ta - tmin) / dt) - 1.f, fhi = floorf((tb - tmin) / dt) + 1.f;
+            lo = (int)fminf(fmaxf(flo, 0.f), 1.0e9f);
+            hi = (int)fminf(fmaxf(fhi, 0.f), 1.0e9f);
+        }
+        if (__ballot(some) != 0ull) {  // wave-uniform
+            const int wlo = uni(wave_min(lo)), whi = uni(wave_max(hi));
+            if (whi >= 65535) ranges_ok = false;
+            __syncthreads();  // every lane has read s_b[c] before slot nh <= c is overwritten
+            if (nh < kMaxList) {
+                if (lane == 0) {
+                    s_b[nh] = k | (slot << 24);
+                    s_a[nh] = min(wlo, 65535) | (min(whi, 65535) << 16);
+                }
+                ++nh;
+            } else if (p.diag && lane == 0) {
+                atomicAdd(p.diag + MVP_DIAG_LIST_OVERFLOW, 1u);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- march ----------------
+    rtmin = fmaxf(rtmin, tmin);  // subset_kernel.h:63-64
+    rtmax = fminf(rtmax, tmax);
+    const bool has = active && (rtmin < INFINITY) && nh > 0;
+    const int incs = has ? (int)fminf(floorf((rtmin - tmin) / dt), 1.0e9f) : 0x7fffffff;  // subset_kernel.h:70
+    const float tend = rtmax + 1e-5f;
+
+    f3 dL3 = mk3(0.f, 0.f, 0.f);
+    float dLw = 0.f;
+    f3 rsat_in = mk3(-1.f, -1.f, -1.f);
+    if (BWD && inimg) {
+        const float4 g4 = reinterpret_cast<const float4 *>(p.grad_rayrgba)[r];  // primaccum.h:58-61
+        dL3 = mk3(g4.x, g4.y, g4.z);
+        dLw = g4.w;
+        rsat_in = ld3(p.raysat_in + r * 3);
+    }
+    const bool has_sat = rsat_in.x > -1.f;  // primaccum.h:93
+
+    if (nh > 0) {
+        if (p.diag && lane == 0) {
+            atomicAdd(p.diag + MVP_DIAG_PACKETS_HIT, 1u);
+            atomicMax(p.diag + MVP_DIAG_MAX_LIST, (uint32_t)nh);
+            if (ncand > kRecSlots) atomicAdd(p.diag + MVP_DIAG_SLOWPATH_PACKETS, 1u);
+        }
+        const size_t V4 = (size_t)p.TD * p.TH * p.TW * 4;
+        const float *T = p.tplate + (size_t)n * K * V4;
+        float *gT = BWD ? p.grad_tplate + (size_t)n * K * V4 : nullptr;
+        const int sW = 4, sH = p.TW * 4, sD = p.TH * p.TW * 4;  // float strides of the channels-last slab
+        const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
+
+        // step window of the packet
+        int s = uni(wave_min(incs));
+        int s_last;
+        {
+            int mylast = -1;
+            for (int j = lane; j < nh; j += kWave) mylast = max(mylast, ranges_ok ? ((s_a[j] >> 16) & 0xffff) : 0x7ffffffe);
+            s_last = uni(wave_max(mylast));
+            // no sample at or beyond t = tend: bound the sweep by the rays' own end as well
+            const int myend = has ? (int)fminf(floorf((tend - tmin) / dt) + 1.f, 1.0e9f) : -1;
+            s_last = min(s_last, uni(wave_max(myend)));
+        }
+        const int nchunks = (nh + kWave - 1) / kWave;
+        bool sat = false;
+
+        while (s <= s_last) {
+            if (__ballot(has && !sat) == 0ull) break;  // every ray saturated (subset_kernel.h:76)
+            const float t = fmaf((float)s, dt, tmin);
+            const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+            const bool inrange = has && s >= incs && t < tend;
+            bool anyslot = false;
+            int nextlo = 0x7fffffff;
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const int j = ch * kWave + lane;
+                bool on = false;
+                if (j < nh) {
+                    const int rg = s_a[j];
+                    const int lo = rg & 0xffff, hi = (rg >> 16) & 0xffff;
+                    on = !ranges_ok || (lo <= s && s <= hi);
+                    if (lo > s) nextlo = min(nextlo, lo);
+                }
+                unsigned long long m = __ballot(on);
+                anyslot = anyslot || (m != 0ull);
+                while (m) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const int ent = uni(s_b[ch * kWave + bit]);
+                    const int k = ent & 0xffffff, slot = (ent >> 24) & 0xff;
+                    const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
+                    const f3 xmt = x - q.pos;
+                    const f3 rxmt = rot_rows(q, xmt);
+                    const f3 y = rxmt * q.scale;
+                    const bool inside = inrange && !sat && y.x > -1.f && y.x < 1.f && y.y > -1.f && y.y < 1.f &&
+                                        y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
+                    if (__ballot(inside) == 0ull) continue;
+
+                    f3 gy = mk3(0.f, 0.f, 0.f);  // BWD: dL/dy of this lane's sample (0 when not inside)
+                    if (inside) {
+                        // ---- fade (primsampler.h:48-51) ----
+                        float fade;
+                        f3 ypow;  // |y|^(fadeexp-1) * sgn(y), backward only
+                        if (FADE8) {
+                            const f3 y2 = y * y, y4 = y2 * y2;
+                            fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+                            if (BWD) ypow = y4 * y2 * y;
+                        } else {
+                            const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
+                            fade = fast_exp(-p.fadescale * (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) +
+                                                            fast_pow(ay.z, p.fadeexp)));
+                            if (BWD) {
+                                const float e1 = p.fadeexp - 1.f;
+                                ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f),
+                                           fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
+                                           fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
+                            }
+                        }
+                        // ---- trilinear, align_corners=True (utils.h:414-468).  y strictly inside (-1,1) puts
+                        //      i in [0, T-1]; clamping the base corner to T-2 keeps all 8 corners in bounds and
+                        //      gives the same value as the reference's zero-padded form (the weight of an
+                        //      out-of-bounds corner is exactly 0 there).
+                        const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
+                        const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
+                        const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
+                        const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
+                                  z0 = min((int)floorf(iz), p.TD - 2);
+                        const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
+                        const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+                        const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+                        const size_t vbase = (size_t)k * V4 + (size_t)z0 * sD + (size_t)y0 * sH + (size_t)x0 * sW;
+                        const float *Tp = T + vbase;
+                        const float4 c000 = *reinterpret_cast<const float4 *>(Tp);
+                        const float4 c001 = *reinterpret_cast<const float4 *>(Tp + sW);
+                        const float4 c010 = *reinterpret_cast<const float4 *>(Tp + sH);
+                        const float4 c011 = *reinterpret_cast<const float4 *>(Tp + sH + sW);
+                        const float4 c100 = *reinterpret_cast<const float4 *>(Tp + sD);
+                        const float4 c101 = *reinterpret_cast<const float4 *>(Tp + sD + sW);
+                        const float4 c110 = *reinterpret_cast<const float4 *>(Tp + sD + sH);
+                        const float4 c111 = *reinterpret_cast<const float4 *>(Tp + sD + sH + sW);
+                        const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
+                                    w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
+                                    w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+                        float4 v;
+                        v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 +
+                              c101.x * w101 + c110.x * w110 + c111.x * w111;
+                        v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 +
+                              c101.y * w101 + c110.y * w110 + c111.y * w111;
+                        v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 +
+                              c101.z * w101 + c110.z * w110 + c111.z * w111;
+                        v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 +
+                              c101.w * w101 + c110.w * w110 + c111.w * w111;
+                        const float alpha = v.w * fade;  // primsampler.h:63
+
+                        if (!BWD) {
+                            // ---- primaccum.h:63-79 ----
+                            const float newalpha = rgba.w + alpha * dt;
+                            const float contrib = fminf(newalpha, 1.f) - rgba.w;
+                            rgba.x += v.x * contrib;
+                            rgba.y += v.y * contrib;
+                            rgba.z += v.z * contrib;
+                            rgba.w += contrib;
+                            if (newalpha >= 1.f) {
+                                raysat = mk3(v.x, v.y, v.z);  // first (and only) time: sat stops further samples
+                                sat = true;
+                            }
+                        } else {
+                            // ---- primaccum.h:81-98 ----
+                            const float a = alpha * dt;
+                            const bool thissat = rgba.w + a >= 1.f;
+                            sat = sat || thissat;
+                            const float weight = sat ? (1.f - rgba.w) : a;
+                            float4 dLs;
+                            dLs.x = weight * dL3.x;
+                            dLs.y = weight * dL3.y;
+                            dLs.z = weight * dL3.z;
+                            dLs.w = sat ? 0.f
+                                        : dt * ((v.x - (has_sat ? rsat_in.x : 0.f)) * dL3.x +
+                                                (v.y - (has_sat ? rsat_in.y : 0.f)) * dL3.y +
+                                                (v.z - (has_sat ? rsat_in.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
+                            rgba.x += v.x * weight;
+                            rgba.y += v.y * weight;
+                            rgba.z += v.z * weight;
+                            rgba.w += weight;
+                            // ---- primsampler.h:70-76 ----
+                            const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                            gy = ypow * gf;
+                            dLs.w *= fade;
+                            // ---- utils.h:582-589: scatter w_c * dL to the 8 corners (32 fp32 atomics) ----
+                            float *Gp = gT + vbase;
+#define MVP_SCATTER(OFF_, WGT_)                           \
+    atomicAdd(Gp + (OFF_) + 0, (WGT_) * dLs.x);           \
+    atomicAdd(Gp + (OFF_) + 1, (WGT_) * dLs.y);           \
+    atomicAdd(Gp + (OFF_) + 2, (WGT_) * dLs.z);           \
+    atomicAdd(Gp + (OFF_) + 3, (WGT_) * dLs.w);
+                            MVP_SCATTER(0, w000)
+                            MVP_SCATTER(sW, w001)
+                            MVP_SCATTER(sH, w010)
+                            MVP_SCATTER(sH + sW, w011)
+                            MVP_SCATTER(sD, w100)
+                            MVP_SCATTER(sD + sW, w101)
+                            MVP_SCATTER(sD + sH, w110)
+                            MVP_SCATTER(sD + sH + sW, w111)
+#undef MVP_SCATTER
+                            // ---- utils.h:592-642: d/d(position) ----
+#define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
+                            const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
+                                        d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
+                                        d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
+#undef MVP_DOT4
+                            const float gix = wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) +
+                                              wy0 * wz1 * (d101 - d100) + wy1 * wz1 * (d111 - d110);
+                            const float giy = wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) +
+                                              wx0 * wz1 * (d110 - d100) + wx1 * wz1 * (d111 - d101);
+                            const float giz = wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) +
+                                              wx0 * wy1 * (d110 - d010) + wx1 * wy1 * (d111 - d011);
+                            gy.x += mx * gix;
+                            gy.y += my * giy;
+                            gy.z += mz * giz;
+                        }
+                    }
+                    if (BWD) {
+                        // ---- primtransf.h:155-179.  grad_scale_j = sum rxmt_j*gy_j, grad_R[i][j] = s_j * sum xmt_i*gy_j,
+                        //      grad_pos_i = -sum_j R[i][j]*s_j * sum gy_j: 12 wave sums, then 15 lanes flush. ----
+                        const float a0 = uni(wave_sum(gy.x)), a1 = uni(wave_sum(gy.y)), a2 = uni(wave_sum(gy.z));
+                        const float c00 = uni(wave_sum(xmt.x * gy.x)), c01 = uni(wave_sum(xmt.x * gy.y)),
+                                    c02 = uni(wave_sum(xmt.x * gy.z));
+                        const float c10 = uni(wave_sum(xmt.y * gy.x)), c11 = uni(wave_sum(xmt.y * gy.y)),
+                                    c12 = uni(wave_sum(xmt.y * gy.z));
+                        const float c20 = uni(wave_sum(xmt.z * gy.x)), c21 = uni(wave_sum(xmt.z * gy.y)),
+                                    c22 = uni(wave_sum(xmt.z * gy.z));
+                        float val = 0.f;
+                        float *dst = nullptr;
+                        const f3 sa = mk3(q.scale.x * a0, q.scale.y * a1, q.scale.z * a2);
+                        switch (lane) {
+                            case 0: val = q.scale.x * c00; break;
+                            case 1: val = q.scale.y * c01; break;
+                            case 2: val = q.scale.z * c02; break;
+                            case 3: val = q.scale.x * c10; break;
+                            case 4: val = q.scale.y * c11; break;
+                            case 5: val = q.scale.z * c12; break;
+                            case 6: val = q.scale.x * c20; break;
+                            case 7: val = q.scale.y * c21; break;
+                            case 8: val = q.scale.z * c22; break;
+                            case 9: val = q.r0.x * c00 + q.r1.x * c10 + q.r2.x * c20; break;   // sum rxmt_x * gy_x
+                            case 10: val = q.r0.y * c01 + q.r1.y * c11 + q.r2.y * c21; break;
+                            case 11: val = q.r0.z * c02 + q.r1.z * c12 + q.r2.z * c22; break;
+                            case 12: val = -dot3(q.r0, sa); break;
+                            case 13: val = -dot3(q.r1, sa); break;
+                            case 14: val = -dot3(q.r2, sa); break;
+                            default: break;
+                        }
+                        if (lane < 9)
+                            dst = p.grad_primrot + ((size_t)n * K + k) * 9 + lane;
+                        else if (lane < 12)
+                            dst = p.grad_primscale + ((size_t)n * K + k) * 3 + (lane - 9);
+                        else if (lane < 15)
+                            dst = p.grad_primpos + ((size_t)n * K + k) * 3 + (lane - 12);
+                        if (dst) atomicAdd(dst, val);
+                    }
+                }
+            }
+            if (anyslot) {
+                ++s;
+            } else {  // nothing listed covers this step: jump to the next range start
+                const int nx = uni(wave_min(nextlo));
+                if (nx == 0x7fffffff) break;
+                s = nx;
+            }
+        }
+    }
+
+    if (!BWD && inimg) {
+        reinterpret_cast<float4 *>(p.rayrgba)[r] = rgba;  // primaccum.h:51-56
+        if (p.raysat) st3(p.raysat + r * 3, raysat);
+    }
+}
+
+}  // namespace mvp
+
+// ------------------------------------------------------------------------------------------------
+static int march_launch(bool bwd, mvp::MarchParams &p, void *stream) {
+    using namespace mvp;
+    if (p.N < 0 || p.H < 0 || p.W < 0 || p.K < 0) return MVP_ERR_BADARG;
+    if ((long long)p.N * p.H * p.W == 0) return MVP_OK;
+    if (!(p.stepsize > 0.f) || !(p.stepsize < INFINITY) || !(p.fadeexp > 0.f) || !(p.fadescale == p.fadescale))
+        return MVP_ERR_BADARG;
+    if (p.K > 0 && (p.TD < 2 || p.TH < 2 || p.TW < 2)) return MVP_ERR_UNSUPPORTED;
+    if (p.K >= (1 << 24)) return MVP_ERR_UNSUPPORTED;  // list entries pack k into 24 bits
+    if (!p.raypos || !p.raydir || !p.tminmax) return MVP_ERR_BADARG;
+    if (p.K > 0 && (!p.nodeaabb || !p.primpos || !p.primrot || !p.primscale || !p.tplate)) return MVP_ERR_BADARG;
+    if (!aligned16(p.tplate) || !aligned16(p.tminmax) || !aligned16(p.nodeaabb)) return MVP_ERR_BADARG;
+    if (bwd) {
+        if (!p.raysat_in || !p.grad_rayrgba) return MVP_ERR_BADARG;
+        if (p.K > 0 && (!p.grad_primpos || !p.grad_primrot || !p.grad_primscale || !p.grad_tplate))
+            return MVP_ERR_BADARG;
+        if (!aligned16(p.grad_rayrgba) || !aligned16(p.grad_tplate)) return MVP_ERR_BADARG;
+        if (p.K == 0) return MVP_OK;
+    } else {
+        if (!p.rayrgba || !aligned16(p.rayrgba)) return MVP_ERR_BADARG;
+    }
+    p.tiles_x = (p.W + kTile - 1) / kTile;
+    p.tiles_y = (p.H + kTile - 1) / kTile;
+    const long long T = (long long)p.tiles_x * p.tiles_y;
+    p.chunk = (int)((T + 7) / 8);
+    const long long blocks = 8ll * p.chunk * p.N;
+    if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
+    if (p.K == 0) {  // nothing to march through: forward output is all zero / raysat -1
+        hipError_t e = hipMemsetAsync(p.rayrgba, 0, sizeof(float) * 4 * (size_t)p.N * p.H * p.W, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        if (p.raysat) {  // -1.0f has no single-byte pattern; K == 0 never happens on the training path
+            return MVP_ERR_UNSUPPORTED;
+        }
+        return MVP_OK;
+    }
+    const bool fade8 = p.fadeexp == 8.0f;
+    const dim3 grid((unsigned)blocks), block(kWave);
+    hipStream_t st = (hipStream_t)stream;
+    if (bwd) {
+        if (fade8)
+            hipLaunchKernelGGL((march_kernel<true, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_kernel<true, false>), grid, block, 0, st, p);
+    } else {
+        if (fade8)
+            hipLaunchKernelGGL((march_kernel<false, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_kernel<false, false>), grid, block, 0, st, p);
+    }
+    return launch_status();
+}
+
+extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir,
+                                 float stepsize, const float *tminmax, const float *nodeaabb, const float *primpos,
+                                 const float *primrot, const float *primscale, int TD, int TH, int TW,
+                                 const float *tplate, float *rayrgba, float *raysat, float fadescale,
+                                 float fadeexp, uint32_t *diag, void *stream) {
+    mvp::MarchParams p = {};
+    p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
+    p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
+    p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
+    p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
+    p.rayrgba = rayrgba, p.raysat = raysat, p.diag = diag;
+    return march_launch(false, p, stream);
+}
+
+extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir,
+                                  float stepsize, const float *tminmax, const float *nodeaabb,
+                                  const float *primpos, const float *primrot, const float *primscale, int TD,
+                                  int TH, int TW, const float *tplate, const float *raysat,
+                                  const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
+                                  float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp,
+                                  uint32_t *diag, void *stream) {
+    mvp::MarchParams p = {};
+    p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
+    p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
+    p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
+    p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
+    p.raysat_in = raysat, p.grad_rayrgba = grad_rayrgba;
+    p.grad_primpos = grad_primpos, p.grad_primrot = grad_primrot, p.grad_primscale = grad_primscale;
+    p.grad_tplate = grad_tplate, p.diag = diag;
+    return march_launch(true, p, stream);
+}

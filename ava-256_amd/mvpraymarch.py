@@ -1,0 +1,232 @@
+"""mvpraymarch -- the MVP raymarch operator with the reference's Python surface
+(extensions/mvpraymarch/mvpraymarch.py:21-84 build_accel, :87-292 MVPRaymarch, :295-390 mvpraymarch),
+running the gfx950 kernels of csrc/{aabb,march}.hip through the C ABI (include/mvp_abi.h).
+
+Differences that are deliberate:
+  * the "fixedorder" tree is an implicit heap, so no sortedobjid / nodechildren / nodeparent tensors are
+    built (the reference builds them with ~10 small torch kernels per call, mvpraymarch.py:44-75);
+  * kernels run on the CURRENT stream, not on legacy stream 0, and nothing is allocated inside the library;
+  * options the reference's kernels ignore (sortprims, maxhitboxes, synchitboxes, accum, termthresh, griddim,
+    blocksize, bwdblocksize: hard-wired template arguments, mvpraymarch_kernel.cu:33,101-102,188-189) are
+    accepted and ignored here too; options that would select code this build does not have raise.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._tensors import aligned, ptr, require_device_f32, stream_ptr
+
+_last_diag = None  # optional device tensor of MVP_DIAG_WORDS uint32 counters (tests / bench only)
+_events = None     # optional list collecting (name, start_event, end_event) per kernel launch (bench only)
+
+
+def set_event_sink(lst):
+    """bench.py: collect HIP events around each C-ABI launch (recorded on the stream the kernel runs on)."""
+    global _events
+    _events = lst
+
+
+class _timed:
+    def __init__(self, name, dev):
+        self.name, self.dev = name, dev
+
+    def __enter__(self):
+        if _events is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.dev))
+
+    def __exit__(self, *exc):
+        if _events is not None:
+            self.b.record(torch.cuda.current_stream(self.dev))
+            _events.append((self.name, self.a, self.b))
+        return False
+
+
+def set_diag_buffer(t):
+    """Give the march kernels a zeroed int32[8] device tensor to accumulate diagnostics into (or None)."""
+    global _last_diag
+    if t is not None:
+        assert t.is_cuda and t.dtype == torch.int32 and t.numel() >= _lib.DIAG_WORDS and t.is_contiguous()
+    _last_diag = t
+
+
+def read_diag():
+    if _last_diag is None:
+        return None
+    v = _last_diag.cpu().tolist()
+    return dict(zip(_lib.DIAG_NAMES, v))
+
+
+def build_accel(primtransfin, algo, fixedorder=False):
+    """AABBs of the fixed-order heap BVH.  Returns (sortedobjid, nodechildren, nodeaabb) like the reference
+    (mvpraymarch.py:84); the first two are None because the topology is implicit (leaf K-1+k = primitive k,
+    children of i are 2i+1 / 2i+2 -- exactly the tensors mvpraymarch.py:45,57-70 would spell out)."""
+    if not fixedorder:
+        raise NotImplementedError(
+            "only usebvh='fixedorder' is implemented: the reference's traversal ignores the LBVH topology "
+            "(utils.h:742,788), so its usebvh=True path walks the wrong tree")
+    primpos, primrot, primscale = primtransfin
+    N, K = primpos.size(0), primpos.size(1)
+    dev = primpos.device
+    nodeaabb = torch.empty((N, K + K - 1, 2, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("aabb_build", dev):
+        _lib.check(_lib.get_lib().mvp_aabb_build(N, K, ptr(primpos), ptr(primrot), ptr(primscale), ptr(nodeaabb),
+                                                stream_ptr(dev)), "mvp_aabb_build")
+    return None, None, nodeaabb
+
+
+class MVPRaymarch(Function):
+    """Custom Function for raymarching Mixture of Volumetric Primitives (same argument list as the reference's
+    MVPRaymarch.forward, mvpraymarch.py:91-93)."""
+
+    @staticmethod
+    def forward(ctx, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, warp, rayterm,
+                gradmode, options):
+        algo = options["algo"]
+        usebvh = options["usebvh"]
+        if warp is not None or algo != 0:
+            raise NotImplementedError("warp-field sampling (algo 1) is not part of this build yet")
+        if usebvh != "fixedorder":
+            raise NotImplementedError("only usebvh='fixedorder' is implemented")
+        if options.get("randomorder", False):
+            raise NotImplementedError("randomorder is not implemented (the reference indexes dim 0 there, "
+                                      "mvpraymarch.py:139-140)")
+        if not options.get("chlast", True):
+            raise NotImplementedError("MVPRaymarch.forward takes channels-last templates; use mvpraymarch(chlast=False)")
+        fadescale, fadeexp = float(options["fadescale"]), float(options["fadeexp"])
+
+        raypos = require_device_f32("raypos", raypos)
+        raydir = require_device_f32("raydir", raydir)
+        tminmax = require_device_f32("tminmax", tminmax)
+        primpos = require_device_f32("primpos", primpos)
+        primrot = require_device_f32("primrot", primrot)
+        primscale = require_device_f32("primscale", primscale)
+        template = require_device_f32("template", template)
+        assert raypos.dim() == 4 and raypos.size(3) == 3
+        assert raydir.shape == raypos.shape
+        assert tminmax.shape == raypos.shape[:3] + (2,)
+        N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
+        K = primpos.size(1)
+        assert primpos.shape == (N, K, 3) and primrot.shape == (N, K, 3, 3) and primscale.shape == (N, K, 3)
+        assert template.dim() == 6 and template.size(-1) == 4 and template.shape[:2] == (N, K)
+        TD, TH, TW = template.size(2), template.size(3), template.size(4)
+        dev = raypos.device
+
+        raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
+        _, _, nodeaabb = build_accel((primpos, primrot, primscale), algo, fixedorder=True)
+
+        rayrgba = torch.empty((N, H, W, 4), device=dev, dtype=torch.float32)
+        raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32) if gradmode else None
+        with torch.cuda.device(dev), _timed("march_forward", dev):
+            _lib.check(_lib.get_lib().mvp_march_forward(
+                N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(rayrgba), ptr(raysat), fadescale,
+                fadeexp, ptr(_last_diag), stream_ptr(dev)), "mvp_march_forward")
+
+        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat)
+        ctx.options = options
+        ctx.stepsize = float(stepsize)
+        return rayrgba
+
+    @staticmethod
+    def backward(ctx, grad_rayrgba):
+        raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat = ctx.saved_tensors
+        if raysat is None:
+            raise RuntimeError("backward through mvpraymarch needs grad mode enabled during the forward call")
+        fadescale, fadeexp = float(ctx.options["fadescale"]), float(ctx.options["fadeexp"])
+        N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
+        K = primpos.size(1)
+        TD, TH, TW = template.size(2), template.size(3), template.size(4)
+        dev = raypos.device
+        grad_rayrgba = aligned(grad_rayrgba.contiguous().float())
+
+        grad_primpos = torch.zeros_like(primpos)
+        grad_primrot = torch.zeros_like(primrot)
+        grad_primscale = torch.zeros_like(primscale)
+        grad_template = torch.zeros_like(template)
+        with torch.cuda.device(dev), _timed("march_backward", dev):
+            _lib.check(_lib.get_lib().mvp_march_backward(
+                N, H, W, K, ptr(raypos), ptr(raydir), ctx.stepsize, ptr(tminmax), ptr(nodeaabb), ptr(primpos),
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(raysat), ptr(grad_rayrgba),
+                ptr(grad_primpos), ptr(grad_primrot), ptr(grad_primscale), ptr(grad_template), fadescale, fadeexp,
+                ptr(_last_diag), stream_ptr(dev)), "mvp_march_backward")
+        return (None, None, None, None, grad_primpos, grad_primrot, grad_primscale, grad_template, None, None,
+                None, None)
+
+
+def mvpraymarch(
+    raypos,
+    raydir,
+    stepsize,
+    tminmax,
+    primtransf,
+    template,
+    warp,
+    rayterm=None,
+    algo=0,
+    usebvh="fixedorder",
+    sortprims=False,
+    randomorder=False,
+    maxhitboxes=512,
+    synchitboxes=True,
+    chlast=True,
+    fadescale=8.0,
+    fadeexp=8.0,
+    accum=0,
+    termthresh=0.0,
+    griddim=3,
+    blocksize=(8, 16),
+    bwdblocksize=(8, 16),
+):
+    """Main entry point for raymarching MVP; parameter names and defaults are the reference's
+    (mvpraymarch.py:295-318) because Raymarcher filters renderoptions by mvpraymarch.__code__.co_varnames.
+
+    raypos, raydir: [N,H,W,3]; tminmax: [N,H,W,2]; primtransf: (primpos [N,K,3], primrot [N,K,3,3],
+    primscale [N,K,3]) or packed [N,K,5,3]; template: [N,K,TD,TH,TW,4] (chlast=True) or [N,K,4,TD,TH,TW];
+    returns rayrgba [N,H,W,4]."""
+    if isinstance(primtransf, tuple):
+        primpos, primrot, primscale = primtransf
+    else:  # packed layout, mvpraymarch.py:355-360
+        primpos, primrot, primscale = (
+            primtransf[:, :, 0, :].contiguous(),
+            primtransf[:, :, 1:4, :].contiguous(),
+            primtransf[:, :, 4, :].contiguous(),
+        )
+    if not chlast:
+        # the reference's kernels only ever read channels-last slabs; do the layout change here, where autograd
+        # carries the gradient back to the caller's layout
+        template = template.permute(0, 1, 3, 4, 5, 2).contiguous()
+        if warp is not None:
+            warp = warp.permute(0, 1, 3, 4, 5, 2).contiguous()
+
+    out = MVPRaymarch.apply(
+        raypos,
+        raydir,
+        stepsize,
+        tminmax,
+        primpos,
+        primrot,
+        primscale,
+        template,
+        warp,
+        rayterm,
+        torch.is_grad_enabled(),
+        {
+            "algo": algo,
+            "usebvh": usebvh,
+            "sortprims": sortprims,
+            "randomorder": randomorder,
+            "maxhitboxes": maxhitboxes,
+            "synchitboxes": synchitboxes,
+            "chlast": True,
+            "fadescale": fadescale,
+            "fadeexp": fadeexp,
+            "accum": accum,
+            "termthresh": termthresh,
+            "griddim": griddim,
+            "blocksize": blocksize,
+            "bwdblocksize": bwdblocksize,
+        },
+    )
+    return out

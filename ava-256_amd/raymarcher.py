@@ -1,0 +1,43 @@
+"""`Raymarcher` -- the nn.Module the autoencoder instantiates (`raymarcherlib.Raymarcher(volradius)`).
+
+API contract taken from the reference (models/raymarchers/mvpraymarcher.py:17-54): constructor
+`(volradius, dt=1.0)`, attributes `volume_radius` and `dt` (= dt / volradius, the march step in volume
+units), and `forward(raypos, raydir, tminmax, decout, renderoptions={}, rayterm=None, with_pos_img=None)`
+returning `(rayrgb [N,3,H,W], rayalpha [N,1,H,W], rayrgba [N,4,H,W] view, None)`.  The module owns no
+parameters or buffers, so `state_dict()` keys of a model that embeds it are unchanged.
+"""
+import inspect
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .mvpraymarch import mvpraymarch
+
+# renderoptions are forwarded only when they name a keyword of mvpraymarch (the reference filters with
+# mvpraymarch.__code__.co_varnames, mvpraymarcher.py:45; the parameter list is the same set of names)
+_OPTION_NAMES = frozenset(inspect.signature(mvpraymarch).parameters) - {
+    "raypos", "raydir", "stepsize", "tminmax", "primtransf", "template", "warp", "rayterm"}
+
+
+def split_rgba_nchw(rayrgba_nhwc: torch.Tensor):
+    """[N,H,W,4] -> (rgb [N,3,H,W] contiguous, alpha [N,1,H,W] contiguous, rgba [N,4,H,W] view)."""
+    nchw = rayrgba_nhwc.movedim(3, 1)
+    return nchw[:, 0:3].contiguous(), nchw[:, 3:4].contiguous(), nchw
+
+
+class Raymarcher(nn.Module):
+    def __init__(self, volradius, dt: float = 1.0):
+        super().__init__()
+        self.volume_radius = volradius
+        self.dt = dt / volradius
+
+    def forward(self, raypos: torch.Tensor, raydir: torch.Tensor, tminmax: torch.Tensor,
+                decout: Dict[str, torch.Tensor], renderoptions: Optional[dict] = {}, rayterm=None,
+                with_pos_img=None):
+        opts = {k: v for k, v in (renderoptions or {}).items() if k in _OPTION_NAMES}
+        prims = (decout["primpos"], decout["primrot"], decout["primscale"])
+        rayrgba = mvpraymarch(raypos, raydir, self.dt, tminmax, prims, template=decout["template"],
+                              warp=decout.get("warp", None), rayterm=rayterm, **opts)
+        rayrgb, rayalpha, rayrgba_nchw = split_rgba_nchw(rayrgba)
+        return rayrgb, rayalpha, rayrgba_nchw, None  # pos_img is always None in the reference as well

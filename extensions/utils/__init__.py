@@ -1,0 +1,1 @@
+"""Import-path compatibility with the reference tree (`extensions.*`): thin re-exports of ava-256_amd."""

@@ -1,0 +1,98 @@
+/*
+ * include/mvp_abi.h -- C ABI of libmvp_gfx950.so, the MI355X-native (gfx950 / CDNA4) replacement of
+ * the reference's two CUDA extensions on the MVP-raymarch training path.
+ *
+ * Drop-in boundary.  The reference binds its kernels through two pybind11 modules:
+ *   mvpraymarchlib {compute_aabb, raymarch_forward, raymarch_backward, (compute_morton, build_tree: dead)}
+ *       /root/reference/extensions/mvpraymarch/mvpraymarch.cpp:398-405
+ *   utilslib       {compute_raydirs_forward, (compute_raydirs_backward: writes nothing)}
+ *       /root/reference/extensions/utils/utils.cpp:134-137
+ * whose bodies unwrap torch::Tensor into raw float and int pointers and call the launchers declared at
+ *   mvpraymarch.cpp:12-100 (compute_aabb_cuda, raymarch_forward_cuda, raymarch_backward_cuda) and
+ *   utils.cpp:12-40      (compute_raydirs_forward_cuda).
+ * The entry points below ARE those launchers, re-cut for HIP: plain pointers + sizes, an explicit
+ * hipStream_t (the reference launches on legacy stream 0: mvpraymarch.cpp:121,141,175,277,393), an int
+ * status instead of silent failure, and no allocation inside the library (the reference's
+ * compute_aabb_cuda does cudaMalloc/cudaMemset/cudaFree per call: bvh.cu:261-263,293).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a dense, contiguous float32 (or uint32) array;
+ *   - the library allocates nothing, keeps no global state and is re-entrant;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream) and the
+ *     call returns without synchronising;
+ *   - return value: MVP_OK (0) or a negative MVP_ERR_* code; positive values are hipError_t codes of a
+ *     failed launch.  mvp_error_string() names either kind.
+ *
+ * Layouts (identical to the tensors the reference's Python hands to its bindings)
+ *   raypos, raydir  [N,H,W,3]   tminmax [N,H,W,2]   rayrgba / grad_rayrgba [N,H,W,4]   raysat [N,H,W,3]
+ *   primpos [N,K,3]  primrot [N,K,3,3] (row-major, rows R0,R1,R2)  primscale [N,K,3] (inverse half-extents)
+ *   tplate / grad_tplate [N,K,TD,TH,TW,4]  (channels-last RGBA slabs, mvpraymarch.py:120-124)
+ *   nodeaabb [N,2K-1,2,3]: implicit heap, internal i -> children 2i+1, 2i+2, leaf node K-1+k = primitive k
+ *                          (the "fixedorder" tree, mvpraymarch.py:44-45,57-75,81)
+ */
+#ifndef MVP_ABI_H_
+#define MVP_ABI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVP_ABI_VERSION 1
+
+#define MVP_OK 0
+#define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
+#define MVP_ERR_UNSUPPORTED (-2) /* a shape this build does not implement (e.g. slab dimension < 2) */
+#define MVP_ERR_NODEVICE (-3)    /* no usable HIP device                                             */
+
+/* number of uint32 words behind the optional `diag` pointer of the march entry points */
+#define MVP_DIAG_WORDS 8
+#define MVP_DIAG_FRONTIER_OVERFLOW 0 /* ray packets whose BVH frontier exceeded the per-packet capacity  */
+#define MVP_DIAG_LIST_OVERFLOW 1     /* ray packets whose hit list exceeded 512 (reference cap, utils.h:779) */
+#define MVP_DIAG_SLOWPATH_PACKETS 2  /* packets that used primitives beyond the LDS-staged record window */
+#define MVP_DIAG_MAX_LIST 3          /* max hit-list length over all packets                             */
+#define MVP_DIAG_PACKETS_HIT 4       /* packets with a non-empty hit list                                */
+
+int mvp_abi_version(void);
+const char *mvp_error_string(int code);
+/* gfx arch name of device `device` into buf (e.g. "gfx950"); MVP_ERR_NODEVICE when there is none. */
+int mvp_device_arch(int device, char *buf, int buflen);
+
+/* Ray generation.  Replaces compute_raydirs_forward_cuda (utils.cpp:12-24, utils_kernel.cu:12-52,97-129).
+ * pixelcoords may be NULL: pixel (w,h) is used (utils_kernel.cu:36).  There is no backward: the
+ * reference's backward kernel writes nothing (utils_kernel.cu:54-95; extensions/utils/utils.py:44-46). */
+int mvp_raydirs_forward(int N, int H, int W, const float *campos /*[N,3]*/, const float *camrot /*[N,3,3]*/,
+                        const float *focal /*[N,2]*/, const float *princpt /*[N,2]*/,
+                        const float *pixelcoords /*[N,H,W,2] or NULL*/, float volradius, float *raypos,
+                        float *raydir, float *tminmax, void *stream);
+
+/* AABBs of the implicit heap BVH.  Replaces compute_aabb_cuda (mvpraymarch.cpp:26-36, bvh.cu:157-201,250-294)
+ * for the "fixedorder" topology, which needs no sortedobjid / nodechildren / nodeparent tensors. */
+int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, const float *primscale,
+                   float *nodeaabb /*[N,2K-1,2,3]*/, void *stream);
+
+/* Forward march.  Replaces raymarch_forward_cuda (mvpraymarch.cpp:38-66, mvpraymarch_kernel.cu:35-120,
+ * mvpraymarch_subset_kernel.h:7-100) for algo 0 / fixedorder / channels-last / additive accumulation,
+ * the only instantiation the training path reaches.  raysat may be NULL (no-grad mode,
+ * mvpraymarch.py:147-152); when given it is fully written (-1 where the ray never saturates).
+ * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
+int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
+                      const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
+                      const float *primscale, int TD, int TH, int TW, const float *tplate, float *rayrgba,
+                      float *raysat, float fadescale, float fadeexp, uint32_t *diag, void *stream);
+
+/* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
+ * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are ACCUMULATED INTO: the caller zero-fills
+ * them (mvpraymarch.py:240-246 does the same with torch.zeros_like). */
+int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
+                       const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
+                       const float *primscale, int TD, int TH, int TW, const float *tplate, const float *raysat,
+                       const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
+                       float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp,
+                       uint32_t *diag, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVP_ABI_H_ */

@@ -1,0 +1,1 @@
+"""Import-path compatibility with the reference tree (`models.raymarchers.mvpraymarcher`)."""
