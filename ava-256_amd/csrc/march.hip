@@ -504,13 +504,15 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
                     if (BWD) {
                         // ---- primtransf.h:155-179.  grad_scale_j = sum rxmt_j*gy_j, grad_R[i][j] = s_j * sum xmt_i*gy_j,
                         //      grad_pos_i = -sum_j R[i][j]*s_j * sum gy_j: 12 wave sums, then 15 lanes flush. ----
+                        // lanes without a sample contribute exact zeros (their x may be inf/NaN: rays outside the image)
+                        const f3 xm = inside ? xmt : mk3(0.f, 0.f, 0.f);
                         const float a0 = uni(wave_sum(gy.x)), a1 = uni(wave_sum(gy.y)), a2 = uni(wave_sum(gy.z));
-                        const float c00 = uni(wave_sum(xmt.x * gy.x)), c01 = uni(wave_sum(xmt.x * gy.y)),
-                                    c02 = uni(wave_sum(xmt.x * gy.z));
-                        const float c10 = uni(wave_sum(xmt.y * gy.x)), c11 = uni(wave_sum(xmt.y * gy.y)),
-                                    c12 = uni(wave_sum(xmt.y * gy.z));
-                        const float c20 = uni(wave_sum(xmt.z * gy.x)), c21 = uni(wave_sum(xmt.z * gy.y)),
-                                    c22 = uni(wave_sum(xmt.z * gy.z));
+                        const float c00 = uni(wave_sum(xm.x * gy.x)), c01 = uni(wave_sum(xm.x * gy.y)),
+                                    c02 = uni(wave_sum(xm.x * gy.z));
+                        const float c10 = uni(wave_sum(xm.y * gy.x)), c11 = uni(wave_sum(xm.y * gy.y)),
+                                    c12 = uni(wave_sum(xm.y * gy.z));
+                        const float c20 = uni(wave_sum(xm.z * gy.x)), c21 = uni(wave_sum(xm.z * gy.y)),
+                                    c22 = uni(wave_sum(xm.z * gy.z));
                         float val = 0.f;
                         float *dst = nullptr;
                         const f3 sa = mk3(q.scale.x * a0, q.scale.y * a1, q.scale.z * a2);

@@ -13,50 +13,8 @@ Differences that are deliberate:
 import torch
 from torch.autograd import Function
 
-from . import _lib
+from . import _hooks, _lib
 from ._tensors import aligned, ptr, require_device_f32, stream_ptr
-
-_last_diag = None  # optional device tensor of MVP_DIAG_WORDS uint32 counters (tests / bench only)
-_events = None     # optional list collecting (name, start_event, end_event) per kernel launch (bench only)
-
-
-def set_event_sink(lst):
-    """bench.py: collect HIP events around each C-ABI launch (recorded on the stream the kernel runs on)."""
-    global _events
-    _events = lst
-
-
-class _timed:
-    def __init__(self, name, dev):
-        self.name, self.dev = name, dev
-
-    def __enter__(self):
-        if _events is not None:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record(torch.cuda.current_stream(self.dev))
-
-    def __exit__(self, *exc):
-        if _events is not None:
-            self.b.record(torch.cuda.current_stream(self.dev))
-            _events.append((self.name, self.a, self.b))
-        return False
-
-
-def set_diag_buffer(t):
-    """Give the march kernels a zeroed int32[8] device tensor to accumulate diagnostics into (or None)."""
-    global _last_diag
-    if t is not None:
-        assert t.is_cuda and t.dtype == torch.int32 and t.numel() >= _lib.DIAG_WORDS and t.is_contiguous()
-    _last_diag = t
-
-
-def read_diag():
-    if _last_diag is None:
-        return None
-    v = _last_diag.cpu().tolist()
-    return dict(zip(_lib.DIAG_NAMES, v))
-
 
 def build_accel(primtransfin, algo, fixedorder=False):
     """AABBs of the fixed-order heap BVH.  Returns (sortedobjid, nodechildren, nodeaabb) like the reference
@@ -70,7 +28,7 @@ def build_accel(primtransfin, algo, fixedorder=False):
     N, K = primpos.size(0), primpos.size(1)
     dev = primpos.device
     nodeaabb = torch.empty((N, K + K - 1, 2, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("aabb_build", dev):
+    with torch.cuda.device(dev), _hooks.timed("aabb_build", dev):
         _lib.check(_lib.get_lib().mvp_aabb_build(N, K, ptr(primpos), ptr(primrot), ptr(primscale), ptr(nodeaabb),
                                                 stream_ptr(dev)), "mvp_aabb_build")
     return None, None, nodeaabb
@@ -118,11 +76,11 @@ class MVPRaymarch(Function):
 
         rayrgba = torch.empty((N, H, W, 4), device=dev, dtype=torch.float32)
         raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32) if gradmode else None
-        with torch.cuda.device(dev), _timed("march_forward", dev):
+        with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
             _lib.check(_lib.get_lib().mvp_march_forward(
                 N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
                 ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(rayrgba), ptr(raysat), fadescale,
-                fadeexp, ptr(_last_diag), stream_ptr(dev)), "mvp_march_forward")
+                fadeexp, ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_forward")
 
         ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat)
         ctx.options = options
@@ -145,12 +103,12 @@ class MVPRaymarch(Function):
         grad_primrot = torch.zeros_like(primrot)
         grad_primscale = torch.zeros_like(primscale)
         grad_template = torch.zeros_like(template)
-        with torch.cuda.device(dev), _timed("march_backward", dev):
+        with torch.cuda.device(dev), _hooks.timed("march_backward", dev):
             _lib.check(_lib.get_lib().mvp_march_backward(
                 N, H, W, K, ptr(raypos), ptr(raydir), ctx.stepsize, ptr(tminmax), ptr(nodeaabb), ptr(primpos),
                 ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(raysat), ptr(grad_rayrgba),
                 ptr(grad_primpos), ptr(grad_primrot), ptr(grad_primscale), ptr(grad_template), fadescale, fadeexp,
-                ptr(_last_diag), stream_ptr(dev)), "mvp_march_backward")
+                ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_backward")
         return (None, None, None, None, grad_primpos, grad_primrot, grad_primscale, grad_template, None, None,
                 None, None)
 

@@ -98,7 +98,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import ava256_amd as ops
-    from ava256_amd import mvpraymarch as mm
+    from ava256_amd import _hooks as mm
     from ava256_amd.scene import make_scene
 
     N, H, W, K, slab = WORKLOADS[args.workload]
