@@ -5,6 +5,8 @@ from . import _lib
 
 diag = None    # device int32[8] the march kernels accumulate MVP_DIAG_* counters into (include/mvp_abi.h)
 events = None  # list collecting (name, start_event, end_event) per C-ABI launch
+force_ray_centric_backward = False  # tests: skip the forward->backward hand-off so the fallback kernel runs
+primlist_cap_override = None        # tests: force a (small) per-primitive list capacity
 
 
 def set_diag_buffer(t):

@@ -18,14 +18,19 @@ SIGNATURES = {
     "mvp_device_arch": (_c_int, [_c_int, ctypes.c_char_p, _c_int]),
     "mvp_raydirs_forward": (_c_int, [_c_int] * 3 + [_c_void_p] * 5 + [_c_float] + [_c_void_p] * 3 + [_c_void_p]),
     "mvp_aabb_build": (_c_int, [_c_int] * 2 + [_c_void_p] * 4 + [_c_void_p]),
+    # N,H,W,K | raypos,raydir | stepsize | tminmax,nodeaabb,primpos,primrot,primscale | TD,TH,TW |
+    # tplate,rayrgba,raysat,rayaux,primlist_count,primlist | primlist_cap | fadescale,fadeexp | diag,stream
     "mvp_march_forward": (_c_int, [_c_int] * 4 + [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 5 + [_c_int] * 3 +
-                          [_c_void_p] * 3 + [_c_float] * 2 + [_c_void_p] * 2),
+                          [_c_void_p] * 6 + [_c_int] + [_c_float] * 2 + [_c_void_p] * 2),
+    # ... | tplate,raysat,rayaux,primlist_count,primlist | primlist_cap | grad_rayrgba,g_pos,g_rot,g_scale,g_tplate |
+    # fadescale,fadeexp | diag,stream
     "mvp_march_backward": (_c_int, [_c_int] * 4 + [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 5 + [_c_int] * 3 +
-                           [_c_void_p] * 7 + [_c_float] * 2 + [_c_void_p] * 2),
+                           [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 5 + [_c_float] * 2 + [_c_void_p] * 2),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 DIAG_WORDS = 8
-DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit"]
+DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
+              "candidates"]
 
 _lib = None
 

@@ -25,8 +25,14 @@
 //     ~150 accumulated fp32 adds (utils: subset_kernel.h:95-96), which is closer to the fp64 truth;
 //   * packets that miss everything exit after the first frontier round (ray compaction by ballot).
 //   * the inside-test guarantees all 8 trilinear corners are in bounds, so the sampler needs no bounds checks.
-//   * backward: template gradients are fp32 hardware atomics (global_atomic_add_f32); the 15 pose gradients
-//     of a (step, primitive) pair are reduced across the wave (12 sufficient sums) and flushed by 15 lanes.
+//   * backward is PRIMITIVE-centric and atomic-free in HBM (bwd_prim_kernel below): the gradient of a sample
+//     does not depend on the running alpha once the forward has recorded, per ray, WHICH sample saturated it
+//     and the alpha just before (rayaux), so samples can be regrouped by primitive.  The forward appends every
+//     (packet, list slot, step range) to a per-primitive list; one workgroup per primitive then stages that
+//     primitive's slab in LDS, re-evaluates its samples ray packet by ray packet, accumulates the slab gradient
+//     with LDS float atomics (ds_add_f32) and writes it back ONCE with coalesced 16-byte stores -- no global
+//     atomics, no zero-fill pass.  The ray-centric backward with global_atomic_add_f32 (march_kernel<true,*>)
+//     is kept as the always-correct fallback for primitives whose list overflowed (device-side flag).
 #include "mvp_device.h"
 #include "mvp_host.h"
 
@@ -48,7 +54,18 @@ struct MarchParams {
     const float *raysat_in, *grad_rayrgba;       // backward inputs
     float *grad_primpos, *grad_primrot, *grad_primscale, *grad_tplate;
     uint32_t *diag;
+    // forward -> backward hand-off (grad mode only; all may be null)
+    uint32_t *rayaux;     // [N,H,W,4]: {satkey, bits(alpha before the saturating sample), first step, bits(tend)}
+    uint32_t *pl_count;   // [N*K + 1]: packets appended per primitive; last word = flags (kFlag*)
+    uint2 *pl_list;       // [N*K, pl_cap]: {(packet << 9) | list slot, lo | hi << 16}
+    int pl_cap;
+    int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
+    int total_packets;    // 8 * chunk * N
 };
+
+constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than pl_cap packets
+constexpr uint32_t kFlagGlobal = 2u;        // a packet produced step indices that do not fit the packed keys
+constexpr uint32_t kNoSat = 0xffffffffu;
 
 struct Rec {  // one primitive's transform, wave-uniform while it is being processed
     f3 pos, r0, r1, r2, scale;
@@ -128,18 +145,17 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d)
     return a;
 }
 
+// One ray packet (8x8 pixels, one wave).  s_a: frontier ping, later packed step ranges (lo | hi << 16);
+// s_b: frontier pong / candidate list / final list (k | slot << 24); s_rec: SRT records of the first 64 candidates.
+// BWD instantiation = ray-centric fallback backward; emit_all: it owns every primitive (else only overflowed ones).
 template <bool BWD, bool FADE8>
-__global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
-    __shared__ int s_a[kMaxList];              // frontier ping; later packed step ranges (lo | hi << 16)
-    __shared__ int s_b[kMaxList];              // frontier pong / candidate list / final list (k | slot << 24)
-    __shared__ float4 s_rec[kRecSlots * 4];    // SRT records of the first 64 candidates (16 floats each)
-
+__device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
+                                             const bool emit_all) {
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt(lane);
 
     // ---- packet -> (image, tile): block b runs on XCD b % 8 (MI355X_MICROARCH "Workgroup dispatch"); give every
     //      XCD a contiguous run of `chunk` row-major packets of each image so its private L2 sees a compact band.
-    const int b = blockIdx.x;
     const int xcd = b & 7, i = b >> 3;
     const int n = i / p.chunk;
     const int tidx = xcd * p.chunk + (i - n * p.chunk);
@@ -170,6 +186,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 
     float4 rgba = make_float4(0.f, 0.f, 0.f, 0.f);
     f3 raysat = mk3(-1.f, -1.f, -1.f);
+    uint32_t satkey = kNoSat;  // (step << 9) | list slot of the saturating sample
+    float wbefore = 0.f;       // alpha just before it
     int nh = 0;            // final list length (wave-uniform)
     int ncand = 0;
 
@@ -303,6 +321,21 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     }
     __syncthreads();
 
+    // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
+    if (!BWD && p.pl_count != nullptr && nh > 0) {
+        uint32_t *flags = p.pl_count + (size_t)p.N * K;
+        for (int j = lane; j < nh; j += kWave) {
+            const int k = s_b[j] & 0xffffff;
+            const size_t pk = (size_t)n * K + k;
+            const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
+            if (idx < (uint32_t)p.pl_cap)
+                p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j]);
+            else
+                atomicOr(flags, kFlagListOverflow);
+        }
+        if (!ranges_ok && lane == 0) atomicOr(flags, kFlagGlobal);
+    }
+
     // ---------------- march ----------------
     rtmin = fmaxf(rtmin, tmin);  // subset_kernel.h:63-64
     rtmax = fminf(rtmax, tmax);
@@ -325,6 +358,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
         if (p.diag && lane == 0) {
             atomicAdd(p.diag + MVP_DIAG_PACKETS_HIT, 1u);
             atomicMax(p.diag + MVP_DIAG_MAX_LIST, (uint32_t)nh);
+            atomicAdd(p.diag + MVP_DIAG_LIST_ENTRIES, (uint32_t)nh);
+            atomicAdd(p.diag + MVP_DIAG_CANDIDATES, (uint32_t)ncand);
             if (ncand > kRecSlots) atomicAdd(p.diag + MVP_DIAG_SLOWPATH_PACKETS, 1u);
         }
         const size_t V4 = (size_t)p.TD * p.TH * p.TW * 4;
@@ -377,6 +412,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
                     const bool inside = inrange && !sat && y.x > -1.f && y.x < 1.f && y.y > -1.f && y.y < 1.f &&
                                         y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
                     if (__ballot(inside) == 0ull) continue;
+                    // fallback backward: only primitives the primitive-centric kernel could not own
+                    const bool emit = !BWD || emit_all || (p.pl_count[(size_t)n * K + k] > (uint32_t)p.pl_cap);
 
                     f3 gy = mk3(0.f, 0.f, 0.f);  // BWD: dL/dy of this lane's sample (0 when not inside)
                     if (inside) {
@@ -445,6 +482,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
                             if (newalpha >= 1.f) {
                                 raysat = mk3(v.x, v.y, v.z);  // first (and only) time: sat stops further samples
                                 sat = true;
+                                satkey = ((uint32_t)s << 9) | (uint32_t)(ch * kWave + bit);
+                                wbefore = rgba.w - contrib;
                             }
                         } else {
                             // ---- primaccum.h:81-98 ----
@@ -464,6 +503,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
                             rgba.y += v.y * weight;
                             rgba.z += v.z * weight;
                             rgba.w += weight;
+                            if (emit) {
                             // ---- primsampler.h:70-76 ----
                             const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
                             gy = ypow * gf;
@@ -499,9 +539,10 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
                             gy.x += mx * gix;
                             gy.y += my * giy;
                             gy.z += mz * giz;
+                            }  // emit
                         }
                     }
-                    if (BWD) {
+                    if (BWD && emit) {
                         // ---- primtransf.h:155-179.  grad_scale_j = sum rxmt_j*gy_j, grad_R[i][j] = s_j * sum xmt_i*gy_j,
                         //      grad_pos_i = -sum_j R[i][j]*s_j * sum gy_j: 12 wave sums, then 15 lanes flush. ----
                         // lanes without a sample contribute exact zeros (their x may be inf/NaN: rays outside the image)
@@ -557,16 +598,254 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     if (!BWD && inimg) {
         reinterpret_cast<float4 *>(p.rayrgba)[r] = rgba;  // primaccum.h:51-56
         if (p.raysat) st3(p.raysat + r * 3, raysat);
+        if (p.rayaux)
+            reinterpret_cast<uint4 *>(p.rayaux)[r] =
+                make_uint4(satkey, __float_as_uint(wbefore), (uint32_t)incs, __float_as_uint(tend));
+    }
+}
+
+template <bool BWD, bool FADE8>
+__global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
+    __shared__ int s_a[kMaxList];
+    __shared__ int s_b[kMaxList];
+    __shared__ float4 s_rec[kRecSlots * 4];
+    if (BWD) {
+        bool emit_all = p.fallback_all != 0;
+        if (!emit_all) {  // nothing to do unless the forward raised a flag
+            const uint32_t flags = p.pl_count[(size_t)p.N * p.K];
+            if (flags == 0u) return;
+            emit_all = (flags & kFlagGlobal) != 0u;
+        }
+        for (int b = blockIdx.x; b < p.total_packets; b += gridDim.x) {
+            march_packet<BWD, FADE8>(p, b, s_a, s_b, s_rec, emit_all);
+            __syncthreads();
+        }
+    } else {
+        march_packet<BWD, FADE8>(p, blockIdx.x, s_a, s_b, s_rec, true);
+    }
+}
+
+
+// =================================================================================================
+// Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
+//   LDS: [V] float4 template slab | [V] float4 gradient slab | 4*12 floats of pose partial sums.
+//   Each wave takes every 4th packet of the primitive's list; its 64 lanes are that packet's rays.
+// Per-sample math: primaccum.h:81-98 with the prefix replaced by the forward's record
+//   key <  satkey : weight = alpha*dt, dL_alpha = dt * dot((rgb,1) - (raysat,1 | 0), dL)
+//   key == satkey : weight = 1 - alpha_before, dL_alpha = 0          (the sample that saturated the ray)
+//   key >  satkey : not evaluated by the forward
+// then primsampler.h:68-91, utils.h:504-643 (scatter into the LDS slab), primtransf.h:155-179 (12 sums).
+// =================================================================================================
+constexpr int kPrimBlock = 256;
+
+template <bool FADE8>
+__global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    const int V = p.TD * p.TH * p.TW;
+    float4 *s_T = smem4;
+    float4 *s_G4 = smem4 + V;
+    float *s_G = reinterpret_cast<float *>(s_G4);
+    float *s_red = reinterpret_cast<float *>(smem4 + 2 * V);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K;
+    // XCD-aware: block b runs on XCD b % 8; give each XCD a contiguous range of k (neighbours on the shell share rays)
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+    const int chunkk = (K + 7) >> 3;
+    const int n = i / chunkk;
+    const int k = xcd * chunkk + (i - n * chunkk);
+    if (k >= K) return;
+    const size_t pk = (size_t)n * K + k;
+
+    const uint32_t flags = p.pl_count[(size_t)p.N * K];
+    const uint32_t cnt = p.pl_count[pk];
+    float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
+    const bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the fallback kernel owns it
+    if (cnt == 0u || dead) {  // this launch doubles as the zero-fill of the gradient buffers
+        for (int v = tid; v < V; v += kPrimBlock) gT4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 9) p.grad_primrot[pk * 9 + tid] = 0.f;
+        if (tid < 3) p.grad_primscale[pk * 3 + tid] = 0.f;
+        if (tid < 3) p.grad_primpos[pk * 3 + tid] = 0.f;
+        return;
+    }
+    {
+        const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
+        for (int v = tid; v < V; v += kPrimBlock) {
+            s_T[v] = T4[v];
+            s_G4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const Rec q = rec_from_global(p.primpos + (size_t)n * K * 3, p.primrot + (size_t)n * K * 9,
+                                  p.primscale + (size_t)n * K * 3, k);
+    __syncthreads();
+
+    const float dt = p.stepsize;
+    const int sW = 1, sH = p.TW, sD = p.TH * p.TW;  // voxel strides
+    const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+    const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
+
+    for (uint32_t e = wave; e < cnt; e += kPrimBlock / kWave) {
+        const uint2 ent = list[e];
+        const int tidx = (int)(ent.x >> 9);
+        const uint32_t slot = ent.x & 511u;
+        const int lo = (int)(ent.y & 0xffffu), hi = (int)(ent.y >> 16);
+        const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
+        const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+        const bool inimg = px < p.W && py < p.H;
+        const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
+        f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+        float tmin = 0.f;
+        f3 dL3 = mk3(0.f, 0.f, 0.f), rsat = mk3(-1.f, -1.f, -1.f);
+        float dLw = 0.f, wbefore = 0.f, tend = -INFINITY;
+        uint32_t satkey = 0u;
+        int incs = 0x7fffffff;
+        if (inimg) {
+            o = ld3(p.raypos + r * 3);
+            d = ld3(p.raydir + r * 3);
+            tmin = p.tminmax[r * 2];
+            const float4 g4 = reinterpret_cast<const float4 *>(p.grad_rayrgba)[r];
+            dL3 = mk3(g4.x, g4.y, g4.z);
+            dLw = g4.w;
+            rsat = ld3(p.raysat_in + r * 3);
+            const uint4 aux = reinterpret_cast<const uint4 *>(p.rayaux)[r];
+            satkey = aux.x;
+            wbefore = __uint_as_float(aux.y);
+            incs = (int)aux.z;
+            tend = __uint_as_float(aux.w);
+        }
+        const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
+        for (int s = lo; s <= hi; ++s) {
+            const float t = fmaf((float)s, dt, tmin);
+            const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+            const f3 xmt = x - q.pos;
+            const f3 rxmt = rot_rows(q, xmt);
+            const f3 y = rxmt * q.scale;
+            const uint32_t key = ((uint32_t)s << 9) | slot;
+            const bool inside = inimg && s >= incs && t < tend && key <= satkey && y.x > -1.f && y.x < 1.f &&
+                                y.y > -1.f && y.y < 1.f && y.z > -1.f && y.z < 1.f;
+            if (__ballot(inside) == 0ull) continue;
+            if (inside) {
+                float fade;
+                f3 ypow;
+                if (FADE8) {
+                    const f3 y2 = y * y, y4 = y2 * y2;
+                    fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+                    ypow = y4 * y2 * y;
+                } else {
+                    const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
+                    fade = fast_exp(-p.fadescale *
+                                    (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) + fast_pow(ay.z, p.fadeexp)));
+                    const float e1 = p.fadeexp - 1.f;
+                    ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f), fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
+                               fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
+                }
+                const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
+                const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
+                const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
+                const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
+                          z0 = min((int)floorf(iz), p.TD - 2);
+                const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
+                const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+                const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+                const int vb = z0 * sD + y0 * sH + x0 * sW;
+                const float4 c000 = s_T[vb], c001 = s_T[vb + sW], c010 = s_T[vb + sH], c011 = s_T[vb + sH + sW];
+                const float4 c100 = s_T[vb + sD], c101 = s_T[vb + sD + sW], c110 = s_T[vb + sD + sH],
+                             c111 = s_T[vb + sD + sH + sW];
+                const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
+                            w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
+                            w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+                float4 v;
+                v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 + c101.x * w101 +
+                      c110.x * w110 + c111.x * w111;
+                v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 + c101.y * w101 +
+                      c110.y * w110 + c111.y * w111;
+                v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 + c101.z * w101 +
+                      c110.z * w110 + c111.z * w111;
+                v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 + c101.w * w101 +
+                      c110.w * w110 + c111.w * w111;
+                const float alpha = v.w * fade;
+                const bool issat = key == satkey;
+                const float weight = issat ? (1.f - wbefore) : alpha * dt;
+                float4 dLs;
+                dLs.x = weight * dL3.x;
+                dLs.y = weight * dL3.y;
+                dLs.z = weight * dL3.z;
+                dLs.w = issat ? 0.f
+                              : dt * ((v.x - (has_sat ? rsat.x : 0.f)) * dL3.x + (v.y - (has_sat ? rsat.y : 0.f)) * dL3.y +
+                                      (v.z - (has_sat ? rsat.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
+                const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                f3 gy = ypow * gf;
+                dLs.w *= fade;
+                float *Gp = s_G + vb * 4;
+#define MVP_LSCATTER(OFF_, WGT_)                         \
+    atomicAdd(Gp + (OFF_)*4 + 0, (WGT_) * dLs.x);        \
+    atomicAdd(Gp + (OFF_)*4 + 1, (WGT_) * dLs.y);        \
+    atomicAdd(Gp + (OFF_)*4 + 2, (WGT_) * dLs.z);        \
+    atomicAdd(Gp + (OFF_)*4 + 3, (WGT_) * dLs.w);
+                MVP_LSCATTER(0, w000)
+                MVP_LSCATTER(sW, w001)
+                MVP_LSCATTER(sH, w010)
+                MVP_LSCATTER(sH + sW, w011)
+                MVP_LSCATTER(sD, w100)
+                MVP_LSCATTER(sD + sW, w101)
+                MVP_LSCATTER(sD + sH, w110)
+                MVP_LSCATTER(sD + sH + sW, w111)
+#undef MVP_LSCATTER
+#define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
+                const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010), d011 = MVP_DOT4(c011),
+                            d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101), d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
+#undef MVP_DOT4
+                gy.x += mx * (wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) + wy0 * wz1 * (d101 - d100) +
+                              wy1 * wz1 * (d111 - d110));
+                gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
+                              wx1 * wz1 * (d111 - d101));
+                gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
+                              wx1 * wy1 * (d111 - d011));
+                a0 += gy.x, a1 += gy.y, a2 += gy.z;
+                c00 += xmt.x * gy.x, c01 += xmt.x * gy.y, c02 += xmt.x * gy.z;
+                c10 += xmt.y * gy.x, c11 += xmt.y * gy.y, c12 += xmt.y * gy.z;
+                c20 += xmt.z * gy.x, c21 += xmt.z * gy.y, c22 += xmt.z * gy.z;
+            }
+        }
+    }
+    // ---- pose gradients: 12 sums per lane -> wave -> workgroup (primtransf.h:155-179) ----
+    {
+        const float sums[12] = {wave_sum(a0),  wave_sum(a1),  wave_sum(a2),  wave_sum(c00), wave_sum(c01), wave_sum(c02),
+                                wave_sum(c10), wave_sum(c11), wave_sum(c12), wave_sum(c20), wave_sum(c21), wave_sum(c22)};
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) s_red[wave * 12 + j] = sums[j];
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v < V; v += kPrimBlock) gT4[v] = s_G4[v];  // the slab gradient, written exactly once
+    if (tid < 12) s_red[48 + tid] = s_red[tid] + s_red[12 + tid] + s_red[24 + tid] + s_red[36 + tid];
+    __syncthreads();
+    if (tid < 15) {
+        const float *Rg = p.primrot + pk * 9, *sg = p.primscale + pk * 3;
+        const float *A = s_red + 48, *C = s_red + 51;  // A[j] = sum gy_j ; C[i*3+j] = sum xmt_i * gy_j
+        if (tid < 9) {
+            p.grad_primrot[pk * 9 + tid] = sg[tid % 3] * C[tid];  // xmt_i * (gy_j * s_j)
+        } else if (tid < 12) {
+            const int j = tid - 9;  // sum_i R[i][j] * C[i][j] = sum rxmt_j * gy_j
+            p.grad_primscale[pk * 3 + j] = Rg[j] * C[j] + Rg[3 + j] * C[3 + j] + Rg[6 + j] * C[6 + j];
+        } else {
+            const int ii = tid - 12;
+            p.grad_primpos[pk * 3 + ii] =
+                -(Rg[ii * 3 + 0] * sg[0] * A[0] + Rg[ii * 3 + 1] * sg[1] * A[1] + Rg[ii * 3 + 2] * sg[2] * A[2]);
+        }
     }
 }
 
 }  // namespace mvp
 
 // ------------------------------------------------------------------------------------------------
-static int march_launch(bool bwd, mvp::MarchParams &p, void *stream) {
+static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     using namespace mvp;
     if (p.N < 0 || p.H < 0 || p.W < 0 || p.K < 0) return MVP_ERR_BADARG;
-    if ((long long)p.N * p.H * p.W == 0) return MVP_OK;
+    if ((long long)p.N * p.H * p.W == 0) return 1;  // nothing to do
     if (!(p.stepsize > 0.f) || !(p.stepsize < INFINITY) || !(p.fadeexp > 0.f) || !(p.fadescale == p.fadescale))
         return MVP_ERR_BADARG;
     if (p.K > 0 && (p.TD < 2 || p.TH < 2 || p.TW < 2)) return MVP_ERR_UNSUPPORTED;
@@ -574,68 +853,76 @@ static int march_launch(bool bwd, mvp::MarchParams &p, void *stream) {
     if (!p.raypos || !p.raydir || !p.tminmax) return MVP_ERR_BADARG;
     if (p.K > 0 && (!p.nodeaabb || !p.primpos || !p.primrot || !p.primscale || !p.tplate)) return MVP_ERR_BADARG;
     if (!aligned16(p.tplate) || !aligned16(p.tminmax) || !aligned16(p.nodeaabb)) return MVP_ERR_BADARG;
-    if (bwd) {
-        if (!p.raysat_in || !p.grad_rayrgba) return MVP_ERR_BADARG;
-        if (p.K > 0 && (!p.grad_primpos || !p.grad_primrot || !p.grad_primscale || !p.grad_tplate))
-            return MVP_ERR_BADARG;
-        if (!aligned16(p.grad_rayrgba) || !aligned16(p.grad_tplate)) return MVP_ERR_BADARG;
-        if (p.K == 0) return MVP_OK;
-    } else {
-        if (!p.rayrgba || !aligned16(p.rayrgba)) return MVP_ERR_BADARG;
-    }
+    if (p.pl_cap < 0) return MVP_ERR_BADARG;
+    if (p.rayaux && !aligned16(p.rayaux)) return MVP_ERR_BADARG;
+    if (p.pl_list && !aligned16(p.pl_list)) return MVP_ERR_BADARG;
     p.tiles_x = (p.W + kTile - 1) / kTile;
     p.tiles_y = (p.H + kTile - 1) / kTile;
     const long long T = (long long)p.tiles_x * p.tiles_y;
     p.chunk = (int)((T + 7) / 8);
     const long long blocks = 8ll * p.chunk * p.N;
     if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
-    if (p.K == 0) {  // nothing to march through: forward output is all zero / raysat -1
-        hipError_t e = hipMemsetAsync(p.rayrgba, 0, sizeof(float) * 4 * (size_t)p.N * p.H * p.W, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-        if (p.raysat) {  // -1.0f has no single-byte pattern; K == 0 never happens on the training path
-            return MVP_ERR_UNSUPPORTED;
-        }
-        return MVP_OK;
-    }
-    const bool fade8 = p.fadeexp == 8.0f;
-    const dim3 grid((unsigned)blocks), block(kWave);
-    hipStream_t st = (hipStream_t)stream;
-    if (bwd) {
-        if (fade8)
-            hipLaunchKernelGGL((march_kernel<true, true>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((march_kernel<true, false>), grid, block, 0, st, p);
-    } else {
-        if (fade8)
-            hipLaunchKernelGGL((march_kernel<false, true>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((march_kernel<false, false>), grid, block, 0, st, p);
-    }
-    return launch_status();
+    p.total_packets = (int)blocks;
+    (void)bwd;
+    return MVP_OK;
 }
 
 extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir,
                                  float stepsize, const float *tminmax, const float *nodeaabb, const float *primpos,
                                  const float *primrot, const float *primscale, int TD, int TH, int TW,
-                                 const float *tplate, float *rayrgba, float *raysat, float fadescale,
+                                 const float *tplate, float *rayrgba, float *raysat, uint32_t *rayaux,
+                                 uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale,
                                  float fadeexp, uint32_t *diag, void *stream) {
-    mvp::MarchParams p = {};
+    using namespace mvp;
+    MarchParams p = {};
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
     p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
     p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
     p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
     p.rayrgba = rayrgba, p.raysat = raysat, p.diag = diag;
-    return march_launch(false, p, stream);
+    p.rayaux = rayaux, p.pl_count = primlist_count, p.pl_list = reinterpret_cast<uint2 *>(primlist);
+    p.pl_cap = primlist_cap;
+    int rc = march_common_checks(false, p);
+    if (rc == 1) return MVP_OK;
+    if (rc != MVP_OK) return rc;
+    if (!rayrgba || !aligned16(rayrgba)) return MVP_ERR_BADARG;
+    if ((primlist_count != nullptr) != (primlist != nullptr)) return MVP_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 0) {  // nothing to march through: all-zero image; raysat would need a -1 fill (never on the training path)
+        if (raysat) return MVP_ERR_UNSUPPORTED;
+        hipError_t e = hipMemsetAsync(rayrgba, 0, sizeof(float) * 4 * (size_t)N * H * W, st);
+        return e == hipSuccess ? MVP_OK : (int)e;
+    }
+    if (p.pl_count) {
+        if ((long long)p.tiles_x * p.tiles_y > (1ll << 23)) {  // packet index does not fit the packed list entry
+            p.pl_count = nullptr, p.pl_list = nullptr;        // backward will see the global flag set below
+        }
+        hipError_t e = hipMemsetAsync(primlist_count, 0, sizeof(uint32_t) * ((size_t)N * K + 1), st);
+        if (e != hipSuccess) return (int)e;
+        if (!p.pl_count) {
+            e = hipMemsetD32Async((hipDeviceptr_t)(primlist_count + (size_t)N * K), (int)kFlagGlobal, 1, st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    const bool fade8 = fadeexp == 8.0f;
+    const dim3 grid((unsigned)p.total_packets), block(kWave);
+    if (fade8)
+        hipLaunchKernelGGL((march_kernel<false, true>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((march_kernel<false, false>), grid, block, 0, st, p);
+    return launch_status();
 }
 
 extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir,
                                   float stepsize, const float *tminmax, const float *nodeaabb,
                                   const float *primpos, const float *primrot, const float *primscale, int TD,
-                                  int TH, int TW, const float *tplate, const float *raysat,
+                                  int TH, int TW, const float *tplate, const float *raysat, const uint32_t *rayaux,
+                                  const uint32_t *primlist_count, const uint32_t *primlist, int primlist_cap,
                                   const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
                                   float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp,
                                   uint32_t *diag, void *stream) {
-    mvp::MarchParams p = {};
+    using namespace mvp;
+    MarchParams p = {};
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
     p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
     p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
@@ -643,5 +930,49 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     p.raysat_in = raysat, p.grad_rayrgba = grad_rayrgba;
     p.grad_primpos = grad_primpos, p.grad_primrot = grad_primrot, p.grad_primscale = grad_primscale;
     p.grad_tplate = grad_tplate, p.diag = diag;
-    return march_launch(true, p, stream);
+    p.rayaux = const_cast<uint32_t *>(rayaux), p.pl_count = const_cast<uint32_t *>(primlist_count);
+    p.pl_list = reinterpret_cast<uint2 *>(const_cast<uint32_t *>(primlist)), p.pl_cap = primlist_cap;
+    int rc = march_common_checks(true, p);
+    if (rc == 1) rc = MVP_OK;  // no rays: the gradients are still defined (all zero) -> fall through to the fill
+    if (rc != MVP_OK) return rc;
+    if (K == 0) return MVP_OK;
+    if (!grad_primpos || !grad_primrot || !grad_primscale || !grad_tplate) return MVP_ERR_BADARG;
+    if (!aligned16(grad_tplate)) return MVP_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V = (size_t)TD * TH * TW;
+    const bool norays = (long long)N * H * W == 0;
+    if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
+    const size_t lds = V * 32 + 64 * sizeof(float);
+    const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
+    const bool prim_path = !norays && have_lists && lds <= 64 * 1024;
+    const bool fade8 = fadeexp == 8.0f;
+    if (!prim_path) {  // ray-centric backward owns everything: it accumulates, so zero-fill first
+        hipError_t e = hipMemsetAsync(grad_tplate, 0, sizeof(float) * 4 * V * (size_t)N * K, st);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_primpos, 0, sizeof(float) * 3 * (size_t)N * K, st);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_primrot, 0, sizeof(float) * 9 * (size_t)N * K, st);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_primscale, 0, sizeof(float) * 3 * (size_t)N * K, st);
+        if (e != hipSuccess) return (int)e;
+        if (norays) return MVP_OK;
+        p.fallback_all = 1;
+    } else {
+        const long long pb = 8ll * ((K + 7) / 8) * N;
+        if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
+        const dim3 grid((unsigned)pb), block(kPrimBlock);
+        if (fade8)
+            hipLaunchKernelGGL((bwd_prim_kernel<true>), grid, block, lds, st, p);
+        else
+            hipLaunchKernelGGL((bwd_prim_kernel<false>), grid, block, lds, st, p);
+        rc = launch_status();
+        if (rc != MVP_OK) return rc;
+        p.fallback_all = 0;
+    }
+    // ray-centric kernel: everything (fallback_all) or only what the forward flagged; exits at once when no flag
+    int fb = p.total_packets;
+    if (!p.fallback_all && fb > 256 * 16) fb = 256 * 16;  // persistent-style grid for the rarely-taken path
+    const dim3 grid((unsigned)fb), block(kWave);
+    if (fade8)
+        hipLaunchKernelGGL((march_kernel<true, true>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((march_kernel<true, false>), grid, block, 0, st, p);
+    return launch_status();
 }

@@ -16,6 +16,18 @@ from torch.autograd import Function
 from . import _hooks, _lib
 from ._tensors import aligned, ptr, require_device_f32, stream_ptr
 
+def primlist_capacity(H, W, K):
+    """Per-primitive capacity of the packet lists handed from forward to backward.  A packet (8x8 pixels) lists
+    about two dozen primitives on head-like scenes, so a primitive is listed by ~24 * packets / K packets;
+    four times that, at least 32.  Primitives that exceed it are handled by the ray-centric kernel (correct, slower)."""
+    if _hooks.primlist_cap_override is not None:
+        return int(_hooks.primlist_cap_override)
+    packets = ((H + 7) // 8) * ((W + 7) // 8)
+    avg = 24.0 * packets / max(K, 1)
+    cap = int(min(max(32, 4 * avg), 2048))
+    return (cap + 7) // 8 * 8
+
+
 def build_accel(primtransfin, algo, fixedorder=False):
     """AABBs of the fixed-order heap BVH.  Returns (sortedobjid, nodechildren, nodeaabb) like the reference
     (mvpraymarch.py:84); the first two are None because the topology is implicit (leaf K-1+k = primitive k,
@@ -75,21 +87,35 @@ class MVPRaymarch(Function):
         _, _, nodeaabb = build_accel((primpos, primrot, primscale), algo, fixedorder=True)
 
         rayrgba = torch.empty((N, H, W, 4), device=dev, dtype=torch.float32)
-        raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32) if gradmode else None
+        raysat = rayaux = pl_count = pl_list = None
+        pl_cap = 0
+        if gradmode:
+            raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
+            if not _hooks.force_ray_centric_backward:
+                # hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record
+                # and, per primitive, the list of ray packets that touch it
+                pl_cap = primlist_capacity(H, W, K)
+                rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
+                pl_count = torch.empty((N * K + 1,), device=dev, dtype=torch.int32)   # zeroed by the library
+                pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
         with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
             _lib.check(_lib.get_lib().mvp_march_forward(
                 N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
-                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(rayrgba), ptr(raysat), fadescale,
-                fadeexp, ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_forward")
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(rayrgba), ptr(raysat), ptr(rayaux),
+                ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag), stream_ptr(dev)),
+                "mvp_march_forward")
 
-        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat)
+        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
+                              pl_count, pl_list)
+        ctx.pl_cap = pl_cap
         ctx.options = options
         ctx.stepsize = float(stepsize)
         return rayrgba
 
     @staticmethod
     def backward(ctx, grad_rayrgba):
-        raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat = ctx.saved_tensors
+        (raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux, pl_count,
+         pl_list) = ctx.saved_tensors
         if raysat is None:
             raise RuntimeError("backward through mvpraymarch needs grad mode enabled during the forward call")
         fadescale, fadeexp = float(ctx.options["fadescale"]), float(ctx.options["fadeexp"])
@@ -99,16 +125,19 @@ class MVPRaymarch(Function):
         dev = raypos.device
         grad_rayrgba = aligned(grad_rayrgba.contiguous().float())
 
-        grad_primpos = torch.zeros_like(primpos)
-        grad_primrot = torch.zeros_like(primrot)
-        grad_primscale = torch.zeros_like(primscale)
-        grad_template = torch.zeros_like(template)
+        # the library overwrites every element of the four gradients: no zero-fill pass (the reference needs
+        # torch.zeros_like x4 here, mvpraymarch.py:240-246)
+        grad_primpos = torch.empty_like(primpos)
+        grad_primrot = torch.empty_like(primrot)
+        grad_primscale = torch.empty_like(primscale)
+        grad_template = torch.empty_like(template)
         with torch.cuda.device(dev), _hooks.timed("march_backward", dev):
             _lib.check(_lib.get_lib().mvp_march_backward(
                 N, H, W, K, ptr(raypos), ptr(raydir), ctx.stepsize, ptr(tminmax), ptr(nodeaabb), ptr(primpos),
-                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(raysat), ptr(grad_rayrgba),
-                ptr(grad_primpos), ptr(grad_primrot), ptr(grad_primscale), ptr(grad_template), fadescale, fadeexp,
-                ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_backward")
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(raysat), ptr(rayaux), ptr(pl_count),
+                ptr(pl_list), ctx.pl_cap, ptr(grad_rayrgba), ptr(grad_primpos), ptr(grad_primrot),
+                ptr(grad_primscale), ptr(grad_template), fadescale, fadeexp, ptr(_hooks.diag), stream_ptr(dev)),
+                "mvp_march_backward")
         return (None, None, None, None, grad_primpos, grad_primrot, grad_primscale, grad_template, None, None,
                 None, None)
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 1
+#define MVP_ABI_VERSION 2
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -53,6 +53,8 @@ extern "C" {
 #define MVP_DIAG_SLOWPATH_PACKETS 2  /* packets that used primitives beyond the LDS-staged record window */
 #define MVP_DIAG_MAX_LIST 3          /* max hit-list length over all packets                             */
 #define MVP_DIAG_PACKETS_HIT 4       /* packets with a non-empty hit list                                */
+#define MVP_DIAG_LIST_ENTRIES 5      /* sum of hit-list lengths over all packets                         */
+#define MVP_DIAG_CANDIDATES 6        /* sum of BVH candidate counts over all packets (before the exact test) */
 
 int mvp_abi_version(void);
 const char *mvp_error_string(int code);
@@ -76,21 +78,32 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  * mvpraymarch_subset_kernel.h:7-100) for algo 0 / fixedorder / channels-last / additive accumulation,
  * the only instantiation the training path reaches.  raysat may be NULL (no-grad mode,
  * mvpraymarch.py:147-152); when given it is fully written (-1 where the ray never saturates).
+ *
+ * Grad-mode hand-off to the backward (all three may be NULL; then the backward uses its ray-centric path):
+ *   rayaux          [N,H,W,4] uint32, fully written: {key of the saturating sample or 0xffffffff,
+ *                   bits(alpha before it), first lattice step, bits(rtmax + 1e-5)}
+ *   primlist_count  [N*K + 1] uint32, zeroed HERE (on `stream`) then filled: packets per primitive; last = flags
+ *   primlist        [N*K, primlist_cap, 2] uint32: per primitive the (packet, list slot, step range) records
  * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
 int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                       const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
                       const float *primscale, int TD, int TH, int TW, const float *tplate, float *rayrgba,
-                      float *raysat, float fadescale, float fadeexp, uint32_t *diag, void *stream);
+                      float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
+                      int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream);
 
 /* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
- * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are ACCUMULATED INTO: the caller zero-fills
- * them (mvpraymarch.py:240-246 does the same with torch.zeros_like). */
+ * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are OVERWRITTEN (every element is written; the
+ * caller need not zero-fill them, unlike mvpraymarch.py:240-246).  With the forward's hand-off buffers the
+ * primitive-centric kernel runs (no HBM atomics); primitives whose list overflowed primlist_cap, or everything
+ * when the buffers are NULL / the slab exceeds the LDS budget, go through the ray-centric kernel with
+ * global_atomic_add_f32. */
 int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                        const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
                        const float *primscale, int TD, int TH, int TW, const float *tplate, const float *raysat,
-                       const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
-                       float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp,
-                       uint32_t *diag, void *stream);
+                       const uint32_t *rayaux, const uint32_t *primlist_count, const uint32_t *primlist,
+                       int primlist_cap, const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
+                       float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp, uint32_t *diag,
+                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -39,12 +39,21 @@ def ops():
     return ava256_amd
 
 
+BACKWARD_MODES = ["prim", "ray", "cap4"]  # primitive-centric | forced ray-centric fallback | tiny list capacity
+
+
 def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, fadescale, fadeexp,
-           grad_out=None):
-    """Run forward (+ backward with grad_out) through the public operator. Inputs: numpy float64/32."""
+           grad_out=None, mode="prim"):
+    """Run forward (+ backward with grad_out) through the public operator. Inputs: numpy float64/32.
+    mode selects the backward implementation under test (all must agree with the oracle):
+      prim: primitive-centric kernel (LDS accumulation); ray: ray-centric kernel with global atomics for
+      everything; cap4: per-primitive list capacity 4, so most primitives overflow into the ray-centric kernel
+      while the rest stay primitive-centric (mixed ownership inside one call)."""
     from ava256_amd import _hooks as mm
     diag = torch.zeros(8, dtype=torch.int32, device="cuda")
     mm.set_diag_buffer(diag)
+    mm.force_ray_centric_backward = (mode == "ray")
+    mm.primlist_cap_override = 4 if mode == "cap4" else None
     t = dict(raypos=to_dev(raypos), raydir=to_dev(raydir), tminmax=to_dev(tminmax), primpos=to_dev(primpos),
              primrot=to_dev(primrot), primscale=to_dev(primscale), template=to_dev(template))
     for k in ("primpos", "primrot", "primscale", "template"):
@@ -61,6 +70,8 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
     torch.cuda.synchronize()
     d = mm.read_diag()
     mm.set_diag_buffer(None)
+    mm.force_ray_centric_backward = False
+    mm.primlist_cap_override = None
     return npf(rgba), grads, d
 
 
@@ -75,13 +86,14 @@ def _check_grads(mine, ref, what=""):
 
 
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
 @pytest.mark.parametrize("name", ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat"])
-def test_march_matches_reference_golden(ops, name):
+def test_march_matches_reference_golden(ops, name, mode):
     """HIP forward + backward vs the fixtures made from mvpraymarch.py:553-641 (float64)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     rgba, grads, diag = _march(ops, g["raypos"], g["raydir"], g["stepsize"], g["tminmax"], g["primpos"],
                                g["primrot"], g["primscale"], g["template"], g["fadescale"], g["fadeexp"],
-                               grad_out=np.ones_like(g["rgba"]))
+                               grad_out=np.ones_like(g["rgba"]), mode=mode)
     assert diag["list_overflow"] == 0 and diag["frontier_overflow"] == 0
     assert np.abs(rgba - g["rgba"]).max() <= FWD_TOL * max(1.0, np.abs(g["rgba"]).max())
     mine = dict(template=grads["template"] * g["chain_template"], primpos=grads["primpos"] * g["chain_primpos"],
@@ -102,8 +114,9 @@ SCENES = [
 ]
 
 
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
 @pytest.mark.parametrize("cfg", SCENES, ids=lambda c: "N%d_%dx%d_K%d_a%g_s%d" % c)
-def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg):
+def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg, mode):
     from ava256_amd.scene import make_scene
     N, H, W, K, again, slab = cfg
     s = make_scene(N, H, W, K, device="cpu", seed=7 + K, alpha_gain=again, slab=slab)
@@ -118,7 +131,7 @@ def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg):
     gout = rng.normal(size=ref_rgba.shape)
     # saturating rays make d(rgba)/d(alpha) jump; compare the backward on the oracle's own raysat
     rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, gout)
-    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=gout)
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=gout, mode=mode)
     assert diag["list_overflow"] == 0 and diag["frontier_overflow"] == 0
     assert diag["packets_hit"] > 0
     scale = max(1.0, np.abs(ref_rgba).max())
