@@ -56,7 +56,7 @@ struct MarchParams {
     uint32_t *diag;
     // forward -> backward hand-off (grad mode only; all may be null)
     uint32_t *rayaux;     // [N,H,W,4]: {satkey, bits(alpha before the saturating sample), first step, bits(tend)}
-    uint32_t *pl_count;   // [N*K + 1]: packets appended per primitive; last word = flags (kFlag*)
+    uint32_t *pl_count;   // [N*K + 3]: packets appended per primitive; then flags (kFlag*), bits(G), bits(Rmax)
     uint2 *pl_list;       // [N*K, pl_cap]: {(packet << 9) | list slot, lo | hi << 16}
     int pl_cap;
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
@@ -628,24 +628,64 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
-//   LDS: [V] float4 template slab | [V] float4 gradient slab | 4*12 floats of pose partial sums.
-//   Each wave takes every 4th packet of the primitive's list; its 64 lanes are that packet's rays.
+//   LDS: [V] float4 template slab | [4][V] int32 gradient "hi" | [4][V] int32 gradient "lo" | small reduce area.
+//   Each wave takes every 4th packet of the primitive's list; its 64 lanes are that packet's rays, each lane
+//   walking ITS OWN lattice steps through the box (lanes are aligned by entry step, not by absolute step).
 // Per-sample math: primaccum.h:81-98 with the prefix replaced by the forward's record
 //   key <  satkey : weight = alpha*dt, dL_alpha = dt * dot((rgb,1) - (raysat,1 | 0), dL)
 //   key == satkey : weight = 1 - alpha_before, dL_alpha = 0          (the sample that saturated the ray)
 //   key >  satkey : not evaluated by the forward
 // then primsampler.h:68-91, utils.h:504-643 (scatter into the LDS slab), primtransf.h:155-179 (12 sums).
+//
+// Slab-gradient accumulation.  Measured on MI355X (tools/ubench/lds_atomic.hip): ds_add_f32 retires ~3 cycles
+// per ACTIVE LANE (193 cycles per wave64 instruction, any address pattern) while ds_add_u32 takes 4.8 cycles per
+// wave instruction when conflict-free.  The 32 contributions of a sample are therefore accumulated in fixed
+// point with integer LDS atomics: value * 2^e -> hi = round(.), lo = trunc(frac * 2^16), two int32 accumulators per
+// slab float.  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed bound B of any
+// single contribution (|hi| <= 2^15), so sums of up to 65536 contributions cannot overflow; the resolution is
+// 2^-31 * B.  Sums are exact integers => the slab gradient is bit-reproducible run to run (the fp32-atomic
+// formulation is not).  Primitives whose sample budget exceeds 65536, or with a non-finite bound, are handed to
+// the ray-centric kernel through the same flag the forward uses for list overflow.
 // =================================================================================================
 constexpr int kPrimBlock = 256;
+constexpr int kFixHiBits = 15;
+constexpr float kFixLoScale = 65536.f;
+constexpr uint32_t kFixMaxSamples = 65536u;
+
+// G = max |grad_rayrgba|, Rmax = max |raysat| -> out[0], out[1] (float bits; non-negative floats order like uints)
+__global__ __launch_bounds__(256) void absmax2_kernel(const float4 *__restrict__ g4, size_t n4,
+                                                      const float *__restrict__ rs, size_t n3,
+                                                      uint32_t *__restrict__ out) {
+    float m0 = 0.f, m1 = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = g4[i];
+        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) m1 = fmaxf(m1, fabsf(rs[i]));
+    m0 = wave_max(m0);
+    m1 = wave_max(m1);
+    if (lane_id() == 0) {
+        // NaN compares false in fmaxf chains above only if it is the first operand; make it sticky as +inf
+        atomicMax(out + 0, __float_as_uint(m0 == m0 ? m0 : INFINITY));
+        atomicMax(out + 1, __float_as_uint(m1 == m1 ? m1 : INFINITY));
+    }
+}
+
+// largest power of two s with B * s < 2^kFixHiBits (B finite, > 0)
+__device__ __forceinline__ float fix_scale(float B) {
+    const int e = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;  // floor(log2 B) for normal B
+    return __uint_as_float((uint32_t)(127 + kFixHiBits - 1 - e) << 23);
+}
 
 template <bool FADE8>
 __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int V = p.TD * p.TH * p.TW;
     float4 *s_T = smem4;
-    float4 *s_G4 = smem4 + V;
-    float *s_G = reinterpret_cast<float *>(s_G4);
-    float *s_red = reinterpret_cast<float *>(smem4 + 2 * V);
+    int *s_hi = reinterpret_cast<int *>(smem4 + V);      // [4][V], channel-planar: consecutive voxels -> consecutive banks
+    int *s_lo = s_hi + 4 * V;
+    float *s_red = reinterpret_cast<float *>(s_lo + 4 * V);  // 64 floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K;
@@ -656,47 +696,87 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
     const int k = xcd * chunkk + (i - n * chunkk);
     if (k >= K) return;
     const size_t pk = (size_t)n * K + k;
+    uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] bits(G), [2] bits(Rmax)
 
-    const uint32_t flags = p.pl_count[(size_t)p.N * K];
+    const uint32_t flags = tail[0];
     const uint32_t cnt = p.pl_count[pk];
     float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
-    const bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the fallback kernel owns it
-    if (cnt == 0u || dead) {  // this launch doubles as the zero-fill of the gradient buffers
+    const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
+    bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
+
+    // ---- stage the slab, its max |rgb|, and this primitive's sample budget ----
+    float tmax = 0.f;
+    uint32_t budget = 0u;
+    if (!dead && cnt > 0u) {
+        const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
+        for (int v = tid; v < V; v += kPrimBlock) {
+            const float4 t = T4[v];
+            s_T[v] = t;
+            tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
+            s_hi[v] = 0, s_hi[V + v] = 0, s_hi[2 * V + v] = 0, s_hi[3 * V + v] = 0;
+            s_lo[v] = 0, s_lo[V + v] = 0, s_lo[2 * V + v] = 0, s_lo[3 * V + v] = 0;
+        }
+        for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
+            const uint32_t rg = list[e].y;
+            budget += ((rg >> 16) - (rg & 0xffffu) + 1u) * 64u;
+        }
+        tmax = wave_max(tmax);
+        budget = (uint32_t)wave_sum((float)min(budget, 1u << 22));  // exact below 2^24; only compared to 2^16
+        if (lane == 0) {
+            s_red[wave] = tmax;
+            s_red[4 + wave] = (float)budget;
+        }
+    }
+    __syncthreads();
+    float s_rgb = 0.f, s_a = 0.f;
+    if (!dead && cnt > 0u) {
+        tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        const float fb = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+        const float G = __uint_as_float(tail[1]), Rmax = __uint_as_float(tail[2]);
+        // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
+        const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
+        if (G == 0.f) {
+            dead = false;
+            s_rgb = s_a = -1.f;  // all-zero upstream gradient: outputs are zero
+        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || fb > (float)kFixMaxSamples) {
+            dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
+            if (tid == 0) {
+                p.pl_count[pk] = 0xffffffffu;
+                atomicOr(tail, kFlagListOverflow);
+            }
+        } else {
+            s_rgb = fix_scale(Brgb);
+            s_a = fix_scale(Ba);
+        }
+    }
+    __syncthreads();  // s_red is reused below
+    if (cnt == 0u || dead || s_rgb < 0.f) {  // this launch doubles as the zero-fill of the gradient buffers
         for (int v = tid; v < V; v += kPrimBlock) gT4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < 9) p.grad_primrot[pk * 9 + tid] = 0.f;
         if (tid < 3) p.grad_primscale[pk * 3 + tid] = 0.f;
         if (tid < 3) p.grad_primpos[pk * 3 + tid] = 0.f;
         return;
     }
-    {
-        const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
-        for (int v = tid; v < V; v += kPrimBlock) {
-            s_T[v] = T4[v];
-            s_G4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     const Rec q = rec_from_global(p.primpos + (size_t)n * K * 3, p.primrot + (size_t)n * K * 9,
                                   p.primscale + (size_t)n * K * 3, k);
-    __syncthreads();
 
     const float dt = p.stepsize;
     const int sW = 1, sH = p.TW, sD = p.TH * p.TW;  // voxel strides
     const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
-    const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
 
     for (uint32_t e = wave; e < cnt; e += kPrimBlock / kWave) {
         const uint2 ent = list[e];
         const int tidx = (int)(ent.x >> 9);
         const uint32_t slot = ent.x & 511u;
-        const int lo = (int)(ent.y & 0xffffu), hi = (int)(ent.y >> 16);
+        const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);
         const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
         const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
         const bool inimg = px < p.W && py < p.H;
         const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
         f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
-        float tmin = 0.f;
+        float tmin = 0.f, tmaxr = -1.f;
         f3 dL3 = mk3(0.f, 0.f, 0.f), rsat = mk3(-1.f, -1.f, -1.f);
         float dLw = 0.f, wbefore = 0.f, tend = -INFINITY;
         uint32_t satkey = 0u;
@@ -704,7 +784,8 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
         if (inimg) {
             o = ld3(p.raypos + r * 3);
             d = ld3(p.raydir + r * 3);
-            tmin = p.tminmax[r * 2];
+            const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
+            tmin = tt.x, tmaxr = tt.y;
             const float4 g4 = reinterpret_cast<const float4 *>(p.grad_rayrgba)[r];
             dL3 = mk3(g4.x, g4.y, g4.z);
             dLw = g4.w;
@@ -716,15 +797,33 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
             tend = __uint_as_float(aux.w);
         }
         const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
-        for (int s = lo; s <= hi; ++s) {
+        // this lane's own lattice-step interval inside the box: the same formulas the forward used to build
+        // the packet range [elo, ehi] (which is the union of these over the packet's lanes)
+        int slo = 1, shi = 0;
+        {
+            const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
+            const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
+            const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
+            const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+            const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+            const float ta = fmaxf(tn, tmin), tb = fminf(tf, tmaxr + 1e-5f);
+            if (inimg && tn <= tf && ta <= tb) {
+                slo = max((int)fminf(fmaxf(floorf((ta - tmin) / dt) - 1.f, 0.f), 1.0e9f), max(elo, incs));
+                shi = min((int)fminf(fmaxf(floorf((tb - tmin) / dt) + 1.f, 0.f), 1.0e9f), ehi);
+            }
+        }
+        const int nsteps = uni(wave_max(shi - slo + 1));
+        for (int it = 0; it < nsteps; ++it) {
+            const int s = slo + it;
             const float t = fmaf((float)s, dt, tmin);
             const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
             const f3 xmt = x - q.pos;
             const f3 rxmt = rot_rows(q, xmt);
             const f3 y = rxmt * q.scale;
             const uint32_t key = ((uint32_t)s << 9) | slot;
-            const bool inside = inimg && s >= incs && t < tend && key <= satkey && y.x > -1.f && y.x < 1.f &&
-                                y.y > -1.f && y.y < 1.f && y.z > -1.f && y.z < 1.f;
+            const bool inside = s <= shi && t < tend && key <= satkey && y.x > -1.f && y.x < 1.f && y.y > -1.f &&
+                                y.y < 1.f && y.z > -1.f && y.z < 1.f;
             if (__ballot(inside) == 0ull) continue;
             if (inside) {
                 float fade;
@@ -778,21 +877,33 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
                 const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
                 f3 gy = ypow * gf;
                 dLs.w *= fade;
-                float *Gp = s_G + vb * 4;
-#define MVP_LSCATTER(OFF_, WGT_)                         \
-    atomicAdd(Gp + (OFF_)*4 + 0, (WGT_) * dLs.x);        \
-    atomicAdd(Gp + (OFF_)*4 + 1, (WGT_) * dLs.y);        \
-    atomicAdd(Gp + (OFF_)*4 + 2, (WGT_) * dLs.z);        \
-    atomicAdd(Gp + (OFF_)*4 + 3, (WGT_) * dLs.w);
-                MVP_LSCATTER(0, w000)
-                MVP_LSCATTER(sW, w001)
-                MVP_LSCATTER(sH, w010)
-                MVP_LSCATTER(sH + sW, w011)
-                MVP_LSCATTER(sD, w100)
-                MVP_LSCATTER(sD + sW, w101)
-                MVP_LSCATTER(sD + sH, w110)
-                MVP_LSCATTER(sD + sH + sW, w111)
+                // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
+                {
+                    const float qx = dLs.x * s_rgb, qy = dLs.y * s_rgb, qz = dLs.z * s_rgb, qw = dLs.w * s_a;  // exact
+                    int *Hp = s_hi + vb, *Lp = s_lo + vb;
+#define MVP_FIX1(OFF_, VAL_)                                                 \
+    {                                                                        \
+        const float a_ = (VAL_);                                             \
+        const float h_ = rintf(a_);                                          \
+        atomicAdd(Hp + (OFF_), (int)h_);                                     \
+        atomicAdd(Lp + (OFF_), (int)((a_ - h_) * kFixLoScale));              \
+    }
+#define MVP_LSCATTER(OFF_, WGT_)              \
+    MVP_FIX1((OFF_), (WGT_) * qx)             \
+    MVP_FIX1((OFF_) + V, (WGT_) * qy)         \
+    MVP_FIX1((OFF_) + 2 * V, (WGT_) * qz)     \
+    MVP_FIX1((OFF_) + 3 * V, (WGT_) * qw)
+                    MVP_LSCATTER(0, w000)
+                    MVP_LSCATTER(sW, w001)
+                    MVP_LSCATTER(sH, w010)
+                    MVP_LSCATTER(sH + sW, w011)
+                    MVP_LSCATTER(sD, w100)
+                    MVP_LSCATTER(sD + sW, w101)
+                    MVP_LSCATTER(sD + sH, w110)
+                    MVP_LSCATTER(sD + sH + sW, w111)
 #undef MVP_LSCATTER
+#undef MVP_FIX1
+                }
 #define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
                 const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010), d011 = MVP_DOT4(c011),
                             d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101), d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
@@ -820,7 +931,17 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
         }
     }
     __syncthreads();
-    for (int v = tid; v < V; v += kPrimBlock) gT4[v] = s_G4[v];  // the slab gradient, written exactly once
+    {  // the slab gradient, written exactly once: (hi + lo / 2^16) / scale
+        const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a, il = 1.0f / kFixLoScale;
+        for (int v = tid; v < V; v += kPrimBlock) {
+            float4 g;
+            g.x = ((float)s_hi[v] + (float)s_lo[v] * il) * i_rgb;
+            g.y = ((float)s_hi[V + v] + (float)s_lo[V + v] * il) * i_rgb;
+            g.z = ((float)s_hi[2 * V + v] + (float)s_lo[2 * V + v] * il) * i_rgb;
+            g.w = ((float)s_hi[3 * V + v] + (float)s_lo[3 * V + v] * il) * i_a;
+            gT4[v] = g;
+        }
+    }
     if (tid < 12) s_red[48 + tid] = s_red[tid] + s_red[12 + tid] + s_red[24 + tid] + s_red[36 + tid];
     __syncthreads();
     if (tid < 15) {
@@ -897,7 +1018,7 @@ extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos
         if ((long long)p.tiles_x * p.tiles_y > (1ll << 23)) {  // packet index does not fit the packed list entry
             p.pl_count = nullptr, p.pl_list = nullptr;        // backward will see the global flag set below
         }
-        hipError_t e = hipMemsetAsync(primlist_count, 0, sizeof(uint32_t) * ((size_t)N * K + 1), st);
+        hipError_t e = hipMemsetAsync(primlist_count, 0, sizeof(uint32_t) * ((size_t)N * K + 3), st);
         if (e != hipSuccess) return (int)e;
         if (!p.pl_count) {
             e = hipMemsetD32Async((hipDeviceptr_t)(primlist_count + (size_t)N * K), (int)kFlagGlobal, 1, st);
@@ -917,7 +1038,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
                                   float stepsize, const float *tminmax, const float *nodeaabb,
                                   const float *primpos, const float *primrot, const float *primscale, int TD,
                                   int TH, int TW, const float *tplate, const float *raysat, const uint32_t *rayaux,
-                                  const uint32_t *primlist_count, const uint32_t *primlist, int primlist_cap,
+                                  uint32_t *primlist_count, const uint32_t *primlist, int primlist_cap,
                                   const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
                                   float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp,
                                   uint32_t *diag, void *stream) {
@@ -930,7 +1051,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     p.raysat_in = raysat, p.grad_rayrgba = grad_rayrgba;
     p.grad_primpos = grad_primpos, p.grad_primrot = grad_primrot, p.grad_primscale = grad_primscale;
     p.grad_tplate = grad_tplate, p.diag = diag;
-    p.rayaux = const_cast<uint32_t *>(rayaux), p.pl_count = const_cast<uint32_t *>(primlist_count);
+    p.rayaux = const_cast<uint32_t *>(rayaux), p.pl_count = primlist_count;
     p.pl_list = reinterpret_cast<uint2 *>(const_cast<uint32_t *>(primlist)), p.pl_cap = primlist_cap;
     int rc = march_common_checks(true, p);
     if (rc == 1) rc = MVP_OK;  // no rays: the gradients are still defined (all zero) -> fall through to the fill
@@ -942,7 +1063,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     const size_t V = (size_t)TD * TH * TW;
     const bool norays = (long long)N * H * W == 0;
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
-    const size_t lds = V * 32 + 64 * sizeof(float);
+    const size_t lds = V * 48 + 64 * sizeof(float);  // float4 slab + 2 x [4][V] int32 + reduce area
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
     const bool prim_path = !norays && have_lists && lds <= 64 * 1024;
     const bool fade8 = fadeexp == 8.0f;
@@ -957,6 +1078,12 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     } else {
         const long long pb = 8ll * ((K + 7) / 8) * N;
         if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
+        // bounds for the fixed-point scales: max |grad_rayrgba| and max |raysat| into the tail of primlist_count
+        hipLaunchKernelGGL(absmax2_kernel, dim3(256 * 8), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(grad_rayrgba), (size_t)N * H * W, raysat,
+                           (size_t)N * H * W * 3, p.pl_count + (size_t)N * K + 1);
+        rc = launch_status();
+        if (rc != MVP_OK) return rc;
         const dim3 grid((unsigned)pb), block(kPrimBlock);
         if (fade8)
             hipLaunchKernelGGL((bwd_prim_kernel<true>), grid, block, lds, st, p);

@@ -96,7 +96,7 @@ class MVPRaymarch(Function):
                 # and, per primitive, the list of ray packets that touch it
                 pl_cap = primlist_capacity(H, W, K)
                 rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
-                pl_count = torch.empty((N * K + 1,), device=dev, dtype=torch.int32)   # zeroed by the library
+                pl_count = torch.empty((N * K + 3,), device=dev, dtype=torch.int32)   # zeroed by the library
                 pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
         with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
             _lib.check(_lib.get_lib().mvp_march_forward(

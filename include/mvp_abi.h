@@ -82,7 +82,8 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  * Grad-mode hand-off to the backward (all three may be NULL; then the backward uses its ray-centric path):
  *   rayaux          [N,H,W,4] uint32, fully written: {key of the saturating sample or 0xffffffff,
  *                   bits(alpha before it), first lattice step, bits(rtmax + 1e-5)}
- *   primlist_count  [N*K + 1] uint32, zeroed HERE (on `stream`) then filled: packets per primitive; last = flags
+ *   primlist_count  [N*K + 3] uint32, zeroed HERE (on `stream`) then filled: packets per primitive; then a flags
+ *                   word and two words the backward uses (max |grad_rayrgba|, max |raysat|)
  *   primlist        [N*K, primlist_cap, 2] uint32: per primitive the (packet, list slot, step range) records
  * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
 int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
@@ -100,7 +101,7 @@ int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const flo
 int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                        const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
                        const float *primscale, int TD, int TH, int TW, const float *tplate, const float *raysat,
-                       const uint32_t *rayaux, const uint32_t *primlist_count, const uint32_t *primlist,
+                       const uint32_t *rayaux, uint32_t *primlist_count, const uint32_t *primlist,
                        int primlist_cap, const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
                        float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp, uint32_t *diag,
                        void *stream);

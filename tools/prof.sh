@@ -6,7 +6,13 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=/tmp/prof_$TAG; rm -rf $OUT; mkdir -p $OUT gpurun_out/$TAG
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python bench.py "$@" > gpurun_out/$TAG/bench.log 2>&1
-find $OUT -name "*stats*.csv" -exec cp {} gpurun_out/$TAG/ \;
-find $OUT -type f | head -20 > gpurun_out/$TAG/files.txt
-tail -1 gpurun_out/$TAG/bench.log | cut -c1-600
-for f in gpurun_out/$TAG/*kernel_stats.csv; do echo "== $f"; head -12 "$f"; done
+find $OUT -name "*kernel_stats.csv" -exec cp {} gpurun_out/$TAG/ \;
+tail -1 gpurun_out/$TAG/bench.log | cut -c1-400
+python - gpurun_out/$TAG/${TAG}_kernel_stats.csv <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+out = [rows[0]] + [[r[0][:90]] + r[1:] for r in rows[1:]]
+csv.writer(open(sys.argv[1], "w")).writerows(out)
+for r in out[:9]:
+    print(" | ".join(x[:70] for x in r[:6]))
+PY
