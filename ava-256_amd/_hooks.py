@@ -7,6 +7,8 @@ diag = None    # device int32[8] the march kernels accumulate MVP_DIAG_* counter
 events = None  # list collecting (name, start_event, end_event) per C-ABI launch
 force_ray_centric_backward = False  # tests: skip the forward->backward hand-off so the fallback kernel runs
 primlist_cap_override = None        # tests: force a (small) per-primitive list capacity
+keep_raysat = False                 # tests: keep the last forward's raysat tensor in `last_raysat`
+last_raysat = None
 
 
 def set_diag_buffer(t):

@@ -33,6 +33,8 @@
 //     with LDS float atomics (ds_add_f32) and writes it back ONCE with coalesced 16-byte stores -- no global
 //     atomics, no zero-fill pass.  The ray-centric backward with global_atomic_add_f32 (march_kernel<true,*>)
 //     is kept as the always-correct fallback for primitives whose list overflowed (device-side flag).
+#include <stdlib.h>
+
 #include "mvp_device.h"
 #include "mvp_host.h"
 
@@ -41,7 +43,7 @@ namespace mvp {
 constexpr int kTile = 8;          // 8x8 pixels per wave
 constexpr int kMaxList = 512;     // reference hit-list cap (mvpraymarch_kernel.cu:101, utils.h:779)
 constexpr int kRecSlots = 64;     // SRT records staged in LDS (first 64 candidates); beyond: scalar global loads
-constexpr int kStartDepth = 6;    // BFS starts with all 64 nodes of depth 6 (one per lane)
+constexpr int kStartDepth = 10;   // the BFS tests every node of this depth first (implicit frontier, <= 1024 nodes)
 constexpr int kNoSlot = 255;
 
 struct MarchParams {
@@ -61,6 +63,7 @@ struct MarchParams {
     int pl_cap;
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
     int total_packets;    // 8 * chunk * N
+    int debug_force_dfs;  // tests: MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
 };
 
 constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than pl_cap packets
@@ -201,24 +204,29 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         pb.thi = uni(wave_max(active ? tmax + 1e-5f : -INFINITY));
 
         // ---------------- breadth-first frontier expansion, lanes over nodes ----------------
+        // The fixed-order heap is a poor BVH near the root (a depth-d node is K/2^d CONSECUTIVE primitives: a ring
+        // of the shell, a row of the UV grid), so its upper levels cull nothing.  The packet therefore tests the
+        // root once (most empty packets leave here), then ALL nodes of depth ds (up to 1024, implicit: nothing is
+        // stored) in 64-lane rounds of independent loads, and only then walks the remaining <= 4 levels with an
+        // explicit, compacted frontier.
         const int dmax = 31 - __clz(NN);  // depth of the deepest node; depth(i) = floor(log2(i+1))
         // leaves sit at depth dmax or dmax-1: start no deeper than dmax-1 so that none is skipped
         const int ds = max(0, min(dmax - 1, kStartDepth));
         int *cur = s_a, *nxt = s_b;
-        int ncur;
-        {
-            const int first = (1 << ds) - 1;
-            ncur = min(1 << ds, NN - first);
-            if (lane < ncur) cur[lane] = first + lane;
-        }
-        __syncthreads();
+        const int first = (1 << ds) - 1;
+        int ncur = min(1 << ds, NN - first);
         bool frontier_ovf = false;
-        for (int dep = ds;; ++dep) {
+        {
+            const float2 *ap = reinterpret_cast<const float2 *>(A);  // root AABB, wave-uniform
+            const float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+            if (!packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y)) ncur = 0;
+        }
+        for (int dep = ds; ncur > 0; ++dep) {
             int nnext = 0;
             for (int base = 0; base < ncur; base += kWave) {
                 const int idx = base + lane;
                 const bool have = idx < ncur;
-                const int e = have ? cur[idx] : 0;
+                const int e = !have ? 0 : (dep == ds ? first + idx : cur[idx]);
                 const bool tested_leaf = e < 0;  // ~node: a leaf that already passed, carried to keep order
                 const int g = tested_leaf ? ~e : e;
                 bool pass = have && tested_leaf;
@@ -235,19 +243,79 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 if (e2 && pos + 1 < kMaxList) nxt[pos + 1] = 2 * g + 2;
                 nnext += __popcll(m1) + __popcll(m2);
             }
-            if (nnext > kMaxList) {
+            if (nnext > kMaxList || p.debug_force_dfs) {
                 frontier_ovf = true;
-                nnext = kMaxList;
+                break;
             }
             __syncthreads();
             int *t = cur;
             cur = nxt;
             nxt = t;
             ncur = nnext;
-            if (ncur == 0 || dep >= dmax) break;
+            if (dep >= dmax) break;
         }
         ncand = ncur;  // entries of `cur` are ~node of tested leaves, in DFS (left-to-right) order
-        if (frontier_ovf && p.diag && lane == 0) atomicAdd(p.diag + MVP_DIAG_FRONTIER_OVERFLOW, 1u);
+        if (frontier_ovf) {
+            // ---- exact fallback: the reference's own traversal (utils.h:733-814): wave-uniform DFS with an explicit
+            //      stack, every lane testing ITS ray against both children (utils.h:679-685), decisions OR-ed over
+            //      the packet.  Slow (one dependent round trip per node) but capacity-free; only heavy scenes get here.
+            if (p.diag && lane == 0) atomicAdd(p.diag + MVP_DIAG_FRONTIER_OVERFLOW, 1u);
+            __syncthreads();
+            int *stack = s_a;  // wave-uniform contents
+            int *cand = s_b;
+            const f3 irdl = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            int sp = 0, node = 0;
+            ncand = 0;
+            while (node != -1) {
+                if (node >= K - 1) {
+                    // leaf: exact ray/box test as in utils.h:744-755 so that only real hits count toward the
+                    // 512-entry capacity (the pass below repeats it to get the step ranges)
+                    const Rec q = rec_from_global(pp, pr, ps, node - (K - 1));
+                    const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
+                    const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
+                    const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
+                    const bool hit = active && max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z)) <=
+                                                   min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+                    if (__ballot(hit) != 0ull) {
+                        if (ncand < kMaxList) {
+                            if (lane == 0) cand[ncand] = ~node;
+                            ++ncand;
+                        } else if (p.diag && lane == 0) {  // the reference drops these too (utils.h:779)
+                            atomicAdd(p.diag + MVP_DIAG_LIST_OVERFLOW, 1u);
+                        }
+                    }
+                    node = sp > 0 ? uni(stack[--sp]) : -1;
+                } else {
+                    const int cl = 2 * node + 1;
+                    const float *bx = A + (size_t)cl * 6;  // both children: 12 consecutive floats, wave-uniform address
+                    bool hl, hr;
+                    {
+                        const f3 t0 = mk3((bx[0] - o.x) * irdl.x, (bx[1] - o.y) * irdl.y, (bx[2] - o.z) * irdl.z);
+                        const f3 t1 = mk3((bx[3] - o.x) * irdl.x, (bx[4] - o.y) * irdl.y, (bx[5] - o.z) * irdl.z);
+                        hl = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z)) <=
+                             min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+                        const f3 u0 = mk3((bx[6] - o.x) * irdl.x, (bx[7] - o.y) * irdl.y, (bx[8] - o.z) * irdl.z);
+                        const f3 u1 = mk3((bx[9] - o.x) * irdl.x, (bx[10] - o.y) * irdl.y, (bx[11] - o.z) * irdl.z);
+                        hr = max3f(fminf(u0.x, u1.x), fminf(u0.y, u1.y), fminf(u0.z, u1.z)) <=
+                             min3f(fmaxf(u0.x, u1.x), fmaxf(u0.y, u1.y), fmaxf(u0.z, u1.z));
+                    }
+                    const bool tl = __ballot(active && hl) != 0ull, tr = __ballot(active && hr) != 0ull;
+                    if (!tl && !tr) {
+                        node = sp > 0 ? uni(stack[--sp]) : -1;
+                    } else {
+                        node = tl ? cl : cl + 1;
+                        if (tl && tr) {  // depth <= 31 < kMaxList entries
+                            if (lane == 0) stack[sp] = cl + 1;
+                            ++sp;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            __syncthreads();
+            cur = cand;
+        }
 
         // move candidates into s_b as primitive indices (cur may be either buffer)
         if (ncand > 0) {
@@ -984,6 +1052,10 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     const long long blocks = 8ll * p.chunk * p.N;
     if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
     p.total_packets = (int)blocks;
+    {
+        const char *e = getenv("MVP_DEBUG_FORCE_DFS");
+        p.debug_force_dfs = (e && e[0] == '1') ? 1 : 0;
+    }
     (void)bwd;
     return MVP_OK;
 }

@@ -105,6 +105,8 @@ class MVPRaymarch(Function):
                 ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag), stream_ptr(dev)),
                 "mvp_march_forward")
 
+        if _hooks.keep_raysat:
+            _hooks.last_raysat = raysat
         ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
                               pl_count, pl_list)
         ctx.pl_cap = pl_cap

@@ -25,7 +25,22 @@ def rodrigues(rvec):
     return R.reshape(rvec.shape[:-1] + (3, 3))
 
 
-def make_primitives(N, K, device="cpu", seed=1112, radius=0.40, slab=8, alpha_gain=1.0, dtype=torch.float32):
+def uvgrid_order(nrm):
+    """Permutation that lists shell points like a row-major UV map: ~sqrt(K) latitude rows, each sorted by
+    azimuth.  ava-256's decoder emits primitives in row-major order of a 2-D UV grid (128 x 128 for K = 16384),
+    so consecutive primitives are neighbours on the surface; the reference's fixed-order heap BVH relies on that.
+    A raw Fibonacci spiral has the opposite property (consecutive points are a golden angle apart)."""
+    K = nrm.shape[0]
+    rows = max(1, int(round(math.sqrt(K))))
+    zrank = torch.argsort(torch.argsort(nrm[:, 2], descending=True))          # 0 = top
+    row = torch.clamp((zrank.to(torch.float64) * rows / K).floor().to(torch.int64), max=rows - 1)
+    az = torch.atan2(nrm[:, 1], nrm[:, 0]).to(torch.float64)
+    key = row.to(torch.float64) * 10.0 + (az + math.pi)                        # az + pi in [0, 2 pi] < 10
+    return torch.argsort(key)
+
+
+def make_primitives(N, K, device="cpu", seed=1112, radius=0.40, slab=8, alpha_gain=1.0, dtype=torch.float32,
+                    order="uvgrid"):
     g = torch.Generator(device=device).manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g, device=device, dtype=dtype)
     # Fibonacci sphere
@@ -34,6 +49,10 @@ def make_primitives(N, K, device="cpu", seed=1112, radius=0.40, slab=8, alpha_ga
     rxy = torch.sqrt(torch.clamp(1 - z * z, min=0))
     phi = i * (math.pi * (3.0 - math.sqrt(5.0)))
     nrm = torch.stack([rxy * torch.cos(phi), rxy * torch.sin(phi), z], dim=-1)  # [K,3] outward normal
+    if order == "uvgrid":
+        nrm = nrm[uvgrid_order(nrm)].contiguous()
+    else:
+        assert order == "fibonacci"  # adversarial for the fixed-order BVH: no locality between consecutive k
     primpos = (radius * nrm)[None].expand(N, K, 3) + 0.002 * rn(N, K, 3)
     # tangent frame: rows (t, b, n) then transposed (columns are the box axes), times a small random rotation
     up = torch.tensor([0.0, 0.0, 1.0], device=device, dtype=dtype).expand(K, 3)
@@ -77,8 +96,8 @@ def pixel_grid(N, H, W, device="cpu", dtype=torch.float32):
     return torch.stack([px, py], dim=-1)[None].expand(N, H, W, 2).contiguous()
 
 
-def make_scene(N, H, W, K, device="cpu", seed=1112, alpha_gain=1.0, slab=8):
-    s = make_primitives(N, K, device=device, seed=seed, alpha_gain=alpha_gain, slab=slab)
+def make_scene(N, H, W, K, device="cpu", seed=1112, alpha_gain=1.0, slab=8, order="uvgrid"):
+    s = make_primitives(N, K, device=device, seed=seed, alpha_gain=alpha_gain, slab=slab, order=order)
     s.update(make_cameras(N, H, W, device=device, seed=seed))
     s["pixelcoords"] = pixel_grid(N, H, W, device=device)
     s.update(N=N, H=H, W=W, K=K)

@@ -48,7 +48,7 @@ extern "C" {
 
 /* number of uint32 words behind the optional `diag` pointer of the march entry points */
 #define MVP_DIAG_WORDS 8
-#define MVP_DIAG_FRONTIER_OVERFLOW 0 /* ray packets whose BVH frontier exceeded the per-packet capacity  */
+#define MVP_DIAG_FRONTIER_OVERFLOW 0 /* ray packets whose BFS frontier exceeded 512 -> exact DFS traversal      */
 #define MVP_DIAG_LIST_OVERFLOW 1     /* ray packets whose hit list exceeded 512 (reference cap, utils.h:779) */
 #define MVP_DIAG_SLOWPATH_PACKETS 2  /* packets that used primitives beyond the LDS-staged record window */
 #define MVP_DIAG_MAX_LIST 3          /* max hit-list length over all packets                             */

@@ -45,6 +45,7 @@ BACKWARD_MODES = ["prim", "ray", "cap4"]  # primitive-centric | forced ray-centr
 def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, fadescale, fadeexp,
            grad_out=None, mode="prim"):
     """Run forward (+ backward with grad_out) through the public operator. Inputs: numpy float64/32.
+    grad_out may be an array or a callable(raysat_numpy) -> array (evaluated after the forward).
     mode selects the backward implementation under test (all must agree with the oracle):
       prim: primitive-centric kernel (LDS accumulation); ray: ray-centric kernel with global atomics for
       everything; cap4: per-primitive list capacity 4, so most primitives overflow into the ray-centric kernel
@@ -54,6 +55,7 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
     mm.set_diag_buffer(diag)
     mm.force_ray_centric_backward = (mode == "ray")
     mm.primlist_cap_override = 4 if mode == "cap4" else None
+    mm.keep_raysat = True
     t = dict(raypos=to_dev(raypos), raydir=to_dev(raydir), tminmax=to_dev(tminmax), primpos=to_dev(primpos),
              primrot=to_dev(primrot), primscale=to_dev(primscale), template=to_dev(template))
     for k in ("primpos", "primrot", "primscale", "template"):
@@ -64,6 +66,8 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
                                fadescale=float(fadescale), fadeexp=float(fadeexp))
     grads = None
     if grad_out is not None:
+        if callable(grad_out):
+            grad_out = grad_out(npf(mm.last_raysat))
         rgba.backward(to_dev(grad_out))
         grads = dict(primpos=npf(t["primpos"].grad), primrot=npf(t["primrot"].grad),
                      primscale=npf(t["primscale"].grad), template=npf(t["template"].grad))
@@ -72,6 +76,8 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
     mm.set_diag_buffer(None)
     mm.force_ray_centric_backward = False
     mm.primlist_cap_override = None
+    mm.keep_raysat = False
+    mm.last_raysat = None
     return npf(rgba), grads, d
 
 
@@ -129,25 +135,51 @@ def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg, mode):
     assert st["list_overflow"] == 0 and st["rays_hit"] > 0
     rng = np.random.default_rng(3)
     gout = rng.normal(size=ref_rgba.shape)
-    # saturating rays make d(rgba)/d(alpha) jump; compare the backward on the oracle's own raysat
-    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, gout)
-    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=gout, mode=mode)
+    # Saturation is a discontinuity of the gradient: a ray whose alpha passes 1.0 by less than fp32 round-off may
+    # saturate at a different sample (or not at all) than in float64.  Such rays are identified from the kernel's
+    # own raysat output and given zero upstream gradient on both sides; they must be rare.
+    fragile = {}
+
+    def masked_gout(hip_raysat):
+        diff = np.abs(hip_raysat - ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(ref_sat).max())
+        fragile["mask"] = diff
+        g = gout.copy()
+        g[diff] = 0.0
+        return g
+
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=masked_gout, mode=mode)
     assert diag["list_overflow"] == 0 and diag["frontier_overflow"] == 0
     assert diag["packets_hit"] > 0
+    fr = fragile["mask"]
+    assert fr.sum() <= max(2, 0.005 * fr.size), fr.sum()
+    g2 = gout.copy()
+    g2[fr] = 0.0
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, g2)
     scale = max(1.0, np.abs(ref_rgba).max())
-    err = np.abs(rgba - ref_rgba)
-    # a ray whose alpha sits within fp32 round-off of 1.0 may saturate one sample earlier/later than in
-    # float64; such rays are compared on alpha only and must be rare
-    near = np.abs(ref_rgba[..., 3] - 1.0) < 1e-5
-    bad = (err.max(-1) > FWD_TOL * scale)
-    assert (bad & ~near).sum() == 0, (err.max(), scale)
-    assert (bad & near).sum() <= max(2, 0.002 * bad.size)
+    err = np.abs(rgba - ref_rgba).max(-1)
+    assert (err[~fr] > FWD_TOL * scale).sum() == 0, (err[~fr].max(), scale)
+    assert np.abs(rgba[..., 3] - ref_rgba[..., 3]).max() <= FWD_TOL          # alpha agrees on fragile rays too
     ref = dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs)
-    if (bad & near).sum() == 0:
-        _check_grads(grads, ref, str(cfg))
-    else:
-        for k in ref:
-            assert cosine(grads[k], ref[k]) >= 0.999, k
+    _check_grads(grads, ref, str(cfg))
+
+
+def test_heavy_scene_takes_the_exact_traversal_fallback(ops, oracle64):
+    """Primitives in raw Fibonacci-spiral order (consecutive k are a golden angle apart): the fixed-order heap has
+    no locality, the BFS frontier exceeds its 512-entry capacity and packets fall back to the reference-style DFS.
+    Hit lists stay far below the 512 cap, so the result must still match the oracle."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(1, 32, 32, 4096, device="cpu", seed=99, alpha_gain=3.0, order="fibonacci")
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(),
+         s["template"].numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a)
+    assert st["list_overflow"] == 0
+    gout = np.random.default_rng(4).normal(size=ref_rgba.shape)
+    ref = dict(zip(("primpos", "primrot", "primscale", "template"), oracle64.march_backward(*a, ref_sat, gout)))
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=gout)
+    assert diag["frontier_overflow"] > 0 and diag["list_overflow"] == 0, diag
+    assert np.abs(rgba - ref_rgba).max() <= FWD_TOL * max(1.0, np.abs(ref_rgba).max())
+    _check_grads(grads, ref, "heavy")
 
 
 def test_no_grad_mode_and_empty_rays(ops):
