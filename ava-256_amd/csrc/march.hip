@@ -696,9 +696,14 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
-//   LDS: [V] float4 template slab | [4][V] int32 gradient "hi" | [4][V] int32 gradient "lo" | small reduce area.
-//   Each wave takes every 4th packet of the primitive's list; its 64 lanes are that packet's rays, each lane
-//   walking ITS OWN lattice steps through the box (lanes are aligned by entry step, not by absolute step).
+//   LDS: [V] float4 template slab | [4][Vp] int32 gradient "hi" | [4][Vp] uint32 gradient "lo" |
+//        ray queue (512 x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + 4, see below).
+//   Work proceeds in rounds of 8 list entries (ray packets):
+//     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
+//             COMPACTED into the LDS queue (ballot + popcount prefix inside the wave, one LDS integer atomic per
+//             wave for the queue tail).  On head-like scenes only ~40 % of a packet's rays cross a given box.
+//     phase 2 (lanes = queued rays, evenly split over the 4 waves): every lane walks ITS OWN lattice steps
+//             through the box (aligned by entry step), samples the LDS slab, scatters into the LDS gradient.
 // Per-sample math: primaccum.h:81-98 with the prefix replaced by the forward's record
 //   key <  satkey : weight = alpha*dt, dL_alpha = dt * dot((rgb,1) - (raysat,1 | 0), dL)
 //   key == satkey : weight = 1 - alpha_before, dL_alpha = 0          (the sample that saturated the ray)
@@ -708,17 +713,21 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // Slab-gradient accumulation.  Measured on MI355X (tools/ubench/lds_atomic.hip): ds_add_f32 retires ~3 cycles
 // per ACTIVE LANE (193 cycles per wave64 instruction, any address pattern) while ds_add_u32 takes 4.8 cycles per
 // wave instruction when conflict-free.  The 32 contributions of a sample are therefore accumulated in fixed
-// point with integer LDS atomics: value * 2^e -> hi = round(.), lo = trunc(frac * 2^16), two int32 accumulators per
-// slab float.  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed bound B of any
-// single contribution (|hi| <= 2^15), so sums of up to 65536 contributions cannot overflow; the resolution is
-// 2^-31 * B.  Sums are exact integers => the slab gradient is bit-reproducible run to run (the fp32-atomic
-// formulation is not).  Primitives whose sample budget exceeds 65536, or with a non-finite bound, are handed to
-// the ray-centric kernel through the same flag the forward uses for list overflow.
+// point with integer LDS atomics: t = int(value * 2^e * 2^16); hi += t >> 16; lo += t & 0xffff (two int32
+// accumulators per slab float).  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed
+// bound B of any single contribution (|value * 2^e| < 2^14), so sums of up to 65536 contributions cannot
+// overflow; the resolution is 2^-30 * B.  Sums are exact integers => the slab gradient is bit-reproducible run
+// to run (the fp32-atomic formulation is not).  Primitives whose sample budget exceeds 65536, or with a
+// non-finite bound, are handed to the ray-centric kernel through the same flag the forward uses for list overflow.
+// The gradient arrays use a z stride of TH*TW + 4 words: the rays of a batch sit on a sheet of cells that is
+// ~5 x 5 in two box axes and straddles two layers of the third; with the natural stride (a multiple of 32 banks)
+// the two layers would collide bank for bank.
 // =================================================================================================
 constexpr int kPrimBlock = 256;
-constexpr int kFixHiBits = 15;
-constexpr float kFixLoScale = 65536.f;
+constexpr int kFixHiBits = 14;
 constexpr uint32_t kFixMaxSamples = 65536u;
+constexpr int kQueueCap = 512;      // rays per round: 8 entries x 64 lanes
+constexpr int kEntriesPerRound = 8;
 
 // G = max |grad_rayrgba|, Rmax = max |raysat| -> out[0], out[1] (float bits; non-negative floats order like uints)
 __global__ __launch_bounds__(256) void absmax2_kernel(const float4 *__restrict__ g4, size_t n4,
@@ -729,20 +738,23 @@ __global__ __launch_bounds__(256) void absmax2_kernel(const float4 *__restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = g4[i];
         m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        if (!(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w)) m0 = INFINITY;  // NaN is sticky
     }
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) m1 = fmaxf(m1, fabsf(rs[i]));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
+        const float v = rs[i];
+        m1 = (v == v) ? fmaxf(m1, fabsf(v)) : INFINITY;
+    }
     m0 = wave_max(m0);
     m1 = wave_max(m1);
     if (lane_id() == 0) {
-        // NaN compares false in fmaxf chains above only if it is the first operand; make it sticky as +inf
-        atomicMax(out + 0, __float_as_uint(m0 == m0 ? m0 : INFINITY));
-        atomicMax(out + 1, __float_as_uint(m1 == m1 ? m1 : INFINITY));
+        atomicMax(out + 0, __float_as_uint(m0));
+        atomicMax(out + 1, __float_as_uint(m1));
     }
 }
 
-// largest power of two s with B * s < 2^kFixHiBits (B finite, > 0)
+// largest power of two s with B * s < 2^kFixHiBits (B finite, normal, > 0)
 __device__ __forceinline__ float fix_scale(float B) {
-    const int e = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;  // floor(log2 B) for normal B
+    const int e = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;  // floor(log2 B)
     return __uint_as_float((uint32_t)(127 + kFixHiBits - 1 - e) << 23);
 }
 
@@ -750,12 +762,17 @@ template <bool FADE8>
 __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int V = p.TD * p.TH * p.TW;
+    const int gH = p.TW, gD = p.TH * p.TW + 4;  // gradient-array strides (words); x stride 1
+    const int Vp = p.TD * gD;
     float4 *s_T = smem4;
-    int *s_hi = reinterpret_cast<int *>(smem4 + V);      // [4][V], channel-planar: consecutive voxels -> consecutive banks
-    int *s_lo = s_hi + 4 * V;
-    float *s_red = reinterpret_cast<float *>(s_lo + 4 * V);  // 64 floats
+    int *s_hi = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar
+    uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_hi + 4 * Vp);
+    uint4 *s_q = reinterpret_cast<uint4 *>(s_lo + 4 * Vp);  // Vp % 4 == 0 keeps this 16-byte aligned
+    float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
+    uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = lanemask_lt(lane);
     const int K = p.K;
     // XCD-aware: block b runs on XCD b % 8; give each XCD a contiguous range of k (neighbours on the shell share rays)
     const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
@@ -781,8 +798,10 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
             const float4 t = T4[v];
             s_T[v] = t;
             tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
-            s_hi[v] = 0, s_hi[V + v] = 0, s_hi[2 * V + v] = 0, s_hi[3 * V + v] = 0;
-            s_lo[v] = 0, s_lo[V + v] = 0, s_lo[2 * V + v] = 0, s_lo[3 * V + v] = 0;
+        }
+        for (int v = tid; v < 4 * Vp; v += kPrimBlock) {
+            s_hi[v] = 0;
+            s_lo[v] = 0u;
         }
         for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
             const uint32_t rg = list[e].y;
@@ -804,17 +823,17 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
         // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
         const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
         if (G == 0.f) {
-            dead = false;
             s_rgb = s_a = -1.f;  // all-zero upstream gradient: outputs are zero
-        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || fb > (float)kFixMaxSamples) {
+        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f) ||
+                   fb > (float)kFixMaxSamples) {
             dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
             if (tid == 0) {
                 p.pl_count[pk] = 0xffffffffu;
                 atomicOr(tail, kFlagListOverflow);
             }
         } else {
-            s_rgb = fix_scale(Brgb);
-            s_a = fix_scale(Ba);
+            s_rgb = fix_scale(Brgb) * 65536.f;  // value -> int(value * s): 16 fractional bits
+            s_a = fix_scale(Ba) * 65536.f;
         }
     }
     __syncthreads();  // s_red is reused below
@@ -829,165 +848,196 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
                                   p.primscale + (size_t)n * K * 3, k);
 
     const float dt = p.stepsize;
-    const int sW = 1, sH = p.TW, sD = p.TH * p.TW;  // voxel strides
+    const int sW = 1, sH = p.TW, sD = p.TH * p.TW;  // voxel strides of the template slab
     const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
-    for (uint32_t e = wave; e < cnt; e += kPrimBlock / kWave) {
-        const uint2 ent = list[e];
-        const int tidx = (int)(ent.x >> 9);
-        const uint32_t slot = ent.x & 511u;
-        const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);
-        const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
-        const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-        const bool inimg = px < p.W && py < p.H;
-        const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
-        f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
-        float tmin = 0.f, tmaxr = -1.f;
-        f3 dL3 = mk3(0.f, 0.f, 0.f), rsat = mk3(-1.f, -1.f, -1.f);
-        float dLw = 0.f, wbefore = 0.f, tend = -INFINITY;
-        uint32_t satkey = 0u;
-        int incs = 0x7fffffff;
-        if (inimg) {
-            o = ld3(p.raypos + r * 3);
-            d = ld3(p.raydir + r * 3);
-            const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
-            tmin = tt.x, tmaxr = tt.y;
-            const float4 g4 = reinterpret_cast<const float4 *>(p.grad_rayrgba)[r];
-            dL3 = mk3(g4.x, g4.y, g4.z);
-            dLw = g4.w;
-            rsat = ld3(p.raysat_in + r * 3);
-            const uint4 aux = reinterpret_cast<const uint4 *>(p.rayaux)[r];
-            satkey = aux.x;
-            wbefore = __uint_as_float(aux.y);
-            incs = (int)aux.z;
-            tend = __uint_as_float(aux.w);
-        }
-        const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
-        // this lane's own lattice-step interval inside the box: the same formulas the forward used to build
-        // the packet range [elo, ehi] (which is the union of these over the packet's lanes)
-        int slo = 1, shi = 0;
-        {
-            const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
-            const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-            const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
-            const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
-            const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
-            const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
-            const float ta = fmaxf(tn, tmin), tb = fminf(tf, tmaxr + 1e-5f);
-            if (inimg && tn <= tf && ta <= tb) {
-                slo = max((int)fminf(fmaxf(floorf((ta - tmin) / dt) - 1.f, 0.f), 1.0e9f), max(elo, incs));
-                shi = min((int)fminf(fmaxf(floorf((tb - tmin) / dt) + 1.f, 0.f), 1.0e9f), ehi);
+    for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
+        if (tid == 0) *s_qn = 0u;
+        __syncthreads();
+        // ---------------- phase 1: which rays of these packets cross the box, and over which steps ----------------
+        const uint32_t eend = min(cnt, ebase + (uint32_t)kEntriesPerRound);
+        for (uint32_t e = ebase + wave; e < eend; e += kPrimBlock / kWave) {
+            const uint2 ent = list[e];
+            const int tidx = (int)(ent.x >> 9);
+            const uint32_t slot = ent.x & 511u;
+            const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);
+            const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
+            const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+            const bool inimg = px < p.W && py < p.H;
+            const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
+            int slo = 1, shi = 0;
+            if (inimg) {
+                const f3 o = ld3(p.raypos + r * 3), d = ld3(p.raydir + r * 3);
+                const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
+                const int incs = (int)p.rayaux[r * 4 + 2];
+                // the same formulas the forward used for the packet range [elo, ehi] (the union of these over lanes)
+                const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
+                const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
+                const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
+                const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+                const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+                const float ta = fmaxf(tn, tt.x), tb = fminf(tf, tt.y + 1e-5f);
+                if (tn <= tf && ta <= tb) {
+                    slo = max((int)fminf(fmaxf(floorf((ta - tt.x) / dt) - 1.f, 0.f), 1.0e9f), max(elo, incs));
+                    shi = min((int)fminf(fmaxf(floorf((tb - tt.x) / dt) + 1.f, 0.f), 1.0e9f), ehi);
+                }
+            }
+            const bool live = slo <= shi;
+            const unsigned long long m = __ballot(live);
+            if (m != 0ull) {
+                uint32_t base = 0u;
+                if (lane == 0) base = atomicAdd(s_qn, (uint32_t)__popcll(m));
+                base = (uint32_t)uni((int)base);
+                if (live)
+                    s_q[base + (uint32_t)__popcll(m & lt)] =
+                        make_uint4((uint32_t)r, (uint32_t)slo | ((uint32_t)(shi - slo + 1) << 16), slot, 0u);
             }
         }
-        const int nsteps = uni(wave_max(shi - slo + 1));
-        for (int it = 0; it < nsteps; ++it) {
-            const int s = slo + it;
-            const float t = fmaf((float)s, dt, tmin);
-            const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
-            const f3 xmt = x - q.pos;
-            const f3 rxmt = rot_rows(q, xmt);
-            const f3 y = rxmt * q.scale;
-            const uint32_t key = ((uint32_t)s << 9) | slot;
-            const bool inside = s <= shi && t < tend && key <= satkey && y.x > -1.f && y.x < 1.f && y.y > -1.f &&
-                                y.y < 1.f && y.z > -1.f && y.z < 1.f;
-            if (__ballot(inside) == 0ull) continue;
-            if (inside) {
-                float fade;
-                f3 ypow;
-                if (FADE8) {
-                    const f3 y2 = y * y, y4 = y2 * y2;
-                    fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
-                    ypow = y4 * y2 * y;
-                } else {
-                    const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
-                    fade = fast_exp(-p.fadescale *
-                                    (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) + fast_pow(ay.z, p.fadeexp)));
-                    const float e1 = p.fadeexp - 1.f;
-                    ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f), fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
-                               fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
-                }
-                const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
-                const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
-                const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
-                const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
-                          z0 = min((int)floorf(iz), p.TD - 2);
-                const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
-                const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
-                const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
-                const int vb = z0 * sD + y0 * sH + x0 * sW;
-                const float4 c000 = s_T[vb], c001 = s_T[vb + sW], c010 = s_T[vb + sH], c011 = s_T[vb + sH + sW];
-                const float4 c100 = s_T[vb + sD], c101 = s_T[vb + sD + sW], c110 = s_T[vb + sD + sH],
-                             c111 = s_T[vb + sD + sH + sW];
-                const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
-                            w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
-                            w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
-                float4 v;
-                v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 + c101.x * w101 +
-                      c110.x * w110 + c111.x * w111;
-                v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 + c101.y * w101 +
-                      c110.y * w110 + c111.y * w111;
-                v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 + c101.z * w101 +
-                      c110.z * w110 + c111.z * w111;
-                v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 + c101.w * w101 +
-                      c110.w * w110 + c111.w * w111;
-                const float alpha = v.w * fade;
-                const bool issat = key == satkey;
-                const float weight = issat ? (1.f - wbefore) : alpha * dt;
-                float4 dLs;
-                dLs.x = weight * dL3.x;
-                dLs.y = weight * dL3.y;
-                dLs.z = weight * dL3.z;
-                dLs.w = issat ? 0.f
-                              : dt * ((v.x - (has_sat ? rsat.x : 0.f)) * dL3.x + (v.y - (has_sat ? rsat.y : 0.f)) * dL3.y +
-                                      (v.z - (has_sat ? rsat.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
-                const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
-                f3 gy = ypow * gf;
-                dLs.w *= fade;
-                // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
-                {
-                    const float qx = dLs.x * s_rgb, qy = dLs.y * s_rgb, qz = dLs.z * s_rgb, qw = dLs.w * s_a;  // exact
-                    int *Hp = s_hi + vb, *Lp = s_lo + vb;
-#define MVP_FIX1(OFF_, VAL_)                                                 \
-    {                                                                        \
-        const float a_ = (VAL_);                                             \
-        const float h_ = rintf(a_);                                          \
-        atomicAdd(Hp + (OFF_), (int)h_);                                     \
-        atomicAdd(Lp + (OFF_), (int)((a_ - h_) * kFixLoScale));              \
+        __syncthreads();
+        // ---------------- phase 2: the queued rays, split evenly over the 4 waves ----------------
+        const int nq = (int)*s_qn;
+        const int per = min(kWave, (nq + 3) >> 2);
+        for (int qb = wave * per; qb < nq; qb += 4 * per) {
+            const bool have = lane < per && qb + lane < nq;
+            const uint4 it = have ? s_q[qb + lane] : make_uint4(0u, 0u, 0u, 0u);
+            const size_t r = it.x;
+            const int slo = (int)(it.y & 0xffffu), len = have ? (int)(it.y >> 16) : 0;
+            const uint32_t slot = it.z;
+            f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+            float tmin = 0.f;
+            f3 dL3 = mk3(0.f, 0.f, 0.f), rsat = mk3(-1.f, -1.f, -1.f);
+            float dLw = 0.f, wbefore = 0.f, tend = -INFINITY;
+            uint32_t satkey = 0u;
+            if (have) {
+                o = ld3(p.raypos + r * 3);
+                d = ld3(p.raydir + r * 3);
+                tmin = p.tminmax[r * 2];
+                const float4 g4 = reinterpret_cast<const float4 *>(p.grad_rayrgba)[r];
+                dL3 = mk3(g4.x, g4.y, g4.z);
+                dLw = g4.w;
+                rsat = ld3(p.raysat_in + r * 3);
+                const uint4 aux = reinterpret_cast<const uint4 *>(p.rayaux)[r];
+                satkey = aux.x;
+                wbefore = __uint_as_float(aux.y);
+                tend = __uint_as_float(aux.w);
+            }
+            const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
+            const int nsteps = uni(wave_max(len));
+            for (int st = 0; st < nsteps; ++st) {
+                const int s = slo + st;
+                const float t = fmaf((float)s, dt, tmin);
+                const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+                const f3 xmt = x - q.pos;
+                const f3 rxmt = rot_rows(q, xmt);
+                const f3 y = rxmt * q.scale;
+                const uint32_t key = ((uint32_t)s << 9) | slot;
+                const bool inside = st < len && t < tend && key <= satkey && y.x > -1.f && y.x < 1.f && y.y > -1.f &&
+                                    y.y < 1.f && y.z > -1.f && y.z < 1.f;
+                if (__ballot(inside) == 0ull) continue;
+                if (inside) {
+                    float fade;
+                    f3 ypow;
+                    if (FADE8) {
+                        const f3 y2 = y * y, y4 = y2 * y2;
+                        fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+                        ypow = y4 * y2 * y;
+                    } else {
+                        const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
+                        fade = fast_exp(-p.fadescale * (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) +
+                                                        fast_pow(ay.z, p.fadeexp)));
+                        const float e1 = p.fadeexp - 1.f;
+                        ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f),
+                                   fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
+                                   fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
+                    }
+                    const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
+                    const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
+                    const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
+                    const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
+                              z0 = min((int)floorf(iz), p.TD - 2);
+                    const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
+                    const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+                    const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+                    const int vb = z0 * sD + y0 * sH + x0 * sW;
+                    const float4 c000 = s_T[vb], c001 = s_T[vb + sW], c010 = s_T[vb + sH], c011 = s_T[vb + sH + sW];
+                    const float4 c100 = s_T[vb + sD], c101 = s_T[vb + sD + sW], c110 = s_T[vb + sD + sH],
+                                 c111 = s_T[vb + sD + sH + sW];
+                    const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
+                                w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
+                                w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+                    float4 v;
+                    v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 +
+                          c101.x * w101 + c110.x * w110 + c111.x * w111;
+                    v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 +
+                          c101.y * w101 + c110.y * w110 + c111.y * w111;
+                    v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 +
+                          c101.z * w101 + c110.z * w110 + c111.z * w111;
+                    v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 +
+                          c101.w * w101 + c110.w * w110 + c111.w * w111;
+                    const float alpha = v.w * fade;
+                    const bool issat = key == satkey;
+                    const float weight = issat ? (1.f - wbefore) : alpha * dt;
+                    float4 dLs;
+                    dLs.x = weight * dL3.x;
+                    dLs.y = weight * dL3.y;
+                    dLs.z = weight * dL3.z;
+                    dLs.w = issat ? 0.f
+                                  : dt * ((v.x - (has_sat ? rsat.x : 0.f)) * dL3.x +
+                                          (v.y - (has_sat ? rsat.y : 0.f)) * dL3.y +
+                                          (v.z - (has_sat ? rsat.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
+                    const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                    f3 gy = ypow * gf;
+                    dLs.w *= fade;
+                    // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
+                    {
+                        const float qx = dLs.x * s_rgb, qy = dLs.y * s_rgb, qz = dLs.z * s_rgb, qw = dLs.w * s_a;  // exact
+                        const int gb = z0 * gD + y0 * gH + x0;
+                        int *Hp = s_hi + gb;
+                        uint32_t *Lp = s_lo + gb;
+#define MVP_FIX1(OFF_, VAL_)                                        \
+    {                                                               \
+        const int t_ = (int)(VAL_);                                 \
+        atomicAdd(Hp + (OFF_), t_ >> 16);                           \
+        atomicAdd(Lp + (OFF_), (uint32_t)t_ & 0xffffu);             \
     }
-#define MVP_LSCATTER(OFF_, WGT_)              \
-    MVP_FIX1((OFF_), (WGT_) * qx)             \
-    MVP_FIX1((OFF_) + V, (WGT_) * qy)         \
-    MVP_FIX1((OFF_) + 2 * V, (WGT_) * qz)     \
-    MVP_FIX1((OFF_) + 3 * V, (WGT_) * qw)
-                    MVP_LSCATTER(0, w000)
-                    MVP_LSCATTER(sW, w001)
-                    MVP_LSCATTER(sH, w010)
-                    MVP_LSCATTER(sH + sW, w011)
-                    MVP_LSCATTER(sD, w100)
-                    MVP_LSCATTER(sD + sW, w101)
-                    MVP_LSCATTER(sD + sH, w110)
-                    MVP_LSCATTER(sD + sH + sW, w111)
+#define MVP_LSCATTER(OFF_, WGT_)               \
+    MVP_FIX1((OFF_), (WGT_) * qx)              \
+    MVP_FIX1((OFF_) + Vp, (WGT_) * qy)         \
+    MVP_FIX1((OFF_) + 2 * Vp, (WGT_) * qz)     \
+    MVP_FIX1((OFF_) + 3 * Vp, (WGT_) * qw)
+                        MVP_LSCATTER(0, w000)
+                        MVP_LSCATTER(1, w001)
+                        MVP_LSCATTER(gH, w010)
+                        MVP_LSCATTER(gH + 1, w011)
+                        MVP_LSCATTER(gD, w100)
+                        MVP_LSCATTER(gD + 1, w101)
+                        MVP_LSCATTER(gD + gH, w110)
+                        MVP_LSCATTER(gD + gH + 1, w111)
 #undef MVP_LSCATTER
 #undef MVP_FIX1
-                }
+                    }
 #define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
-                const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010), d011 = MVP_DOT4(c011),
-                            d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101), d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
+                    const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
+                                d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
+                                d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
 #undef MVP_DOT4
-                gy.x += mx * (wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) + wy0 * wz1 * (d101 - d100) +
-                              wy1 * wz1 * (d111 - d110));
-                gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
-                              wx1 * wz1 * (d111 - d101));
-                gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
-                              wx1 * wy1 * (d111 - d011));
-                a0 += gy.x, a1 += gy.y, a2 += gy.z;
-                c00 += xmt.x * gy.x, c01 += xmt.x * gy.y, c02 += xmt.x * gy.z;
-                c10 += xmt.y * gy.x, c11 += xmt.y * gy.y, c12 += xmt.y * gy.z;
-                c20 += xmt.z * gy.x, c21 += xmt.z * gy.y, c22 += xmt.z * gy.z;
+                    gy.x += mx * (wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) + wy0 * wz1 * (d101 - d100) +
+                                  wy1 * wz1 * (d111 - d110));
+                    gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
+                                  wx1 * wz1 * (d111 - d101));
+                    gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
+                                  wx1 * wy1 * (d111 - d011));
+                    a0 += gy.x, a1 += gy.y, a2 += gy.z;
+                    c00 += xmt.x * gy.x, c01 += xmt.x * gy.y, c02 += xmt.x * gy.z;
+                    c10 += xmt.y * gy.x, c11 += xmt.y * gy.y, c12 += xmt.y * gy.z;
+                    c20 += xmt.z * gy.x, c21 += xmt.z * gy.y, c22 += xmt.z * gy.z;
+                }
             }
         }
+        __syncthreads();  // the queue is rewritten by the next round
     }
     // ---- pose gradients: 12 sums per lane -> wave -> workgroup (primtransf.h:155-179) ----
     {
@@ -999,14 +1049,16 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
         }
     }
     __syncthreads();
-    {  // the slab gradient, written exactly once: (hi + lo / 2^16) / scale
-        const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a, il = 1.0f / kFixLoScale;
+    {  // the slab gradient, written exactly once: (hi * 2^16 + lo) / scale
+        const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
         for (int v = tid; v < V; v += kPrimBlock) {
+            const int z = v / sD, rem = v - z * sD;
+            const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
-            g.x = ((float)s_hi[v] + (float)s_lo[v] * il) * i_rgb;
-            g.y = ((float)s_hi[V + v] + (float)s_lo[V + v] * il) * i_rgb;
-            g.z = ((float)s_hi[2 * V + v] + (float)s_lo[2 * V + v] * il) * i_rgb;
-            g.w = ((float)s_hi[3 * V + v] + (float)s_lo[3 * V + v] * il) * i_a;
+            g.x = ((float)s_hi[gv] * 65536.f + (float)s_lo[gv]) * i_rgb;
+            g.y = ((float)s_hi[Vp + gv] * 65536.f + (float)s_lo[Vp + gv]) * i_rgb;
+            g.z = ((float)s_hi[2 * Vp + gv] * 65536.f + (float)s_lo[2 * Vp + gv]) * i_rgb;
+            g.w = ((float)s_hi[3 * Vp + gv] * 65536.f + (float)s_lo[3 * Vp + gv]) * i_a;
             gT4[v] = g;
         }
     }
@@ -1135,7 +1187,9 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     const size_t V = (size_t)TD * TH * TW;
     const bool norays = (long long)N * H * W == 0;
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
-    const size_t lds = V * 48 + 64 * sizeof(float);  // float4 slab + 2 x [4][V] int32 + reduce area
+    const size_t Vp = (size_t)TD * ((size_t)TH * TW + 4);
+    // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
+    const size_t lds = V * 16 + Vp * 32 + 512 * 16 + 64 * sizeof(float) + 16;
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
     const bool prim_path = !norays && have_lists && lds <= 64 * 1024;
     const bool fade8 = fadeexp == 8.0f;
