@@ -151,6 +151,22 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d)
 // One ray packet (8x8 pixels, one wave).  s_a: frontier ping, later packed step ranges (lo | hi << 16);
 // s_b: frontier pong / candidate list / final list (k | slot << 24); s_rec: SRT records of the first 64 candidates.
 // BWD instantiation = ray-centric fallback backward; emit_all: it owns every primitive (else only overflowed ones).
+// Lattice steps s (t_s = tmin + s*dt) of one ray that can fall strictly inside a box whose slab interval is
+// [tn, tf] (utils.h:747-753), clipped to the ray's [tmin, tmax + 1e-5).  The strict inside test on the evaluated
+// position decides membership exactly as in the reference; this range only has to contain every step that test
+// can accept, so it is the analytic range widened by a slack that covers fp32 rounding of t and of the slab test
+// (a few 1e-7 * |t| / dt steps) -- not by whole steps, which would waste one third of the march iterations.
+__device__ __forceinline__ bool lane_step_range(float tn, float tf, float tmin, float tmax, float dt, int &lo,
+                                                int &hi) {
+    const float ta = fmaxf(tn, tmin), tb = fminf(tf, tmax + 1e-5f);
+    if (!(tn <= tf) || !(ta <= tb)) return false;
+    const float slack = 0.02f + 2.0e-6f * fmaxf(fmaxf(fabsf(ta), fabsf(tb)), 1.f) / dt;
+    const float flo = ceilf((ta - tmin) / dt - slack), fhi = floorf((tb - tmin) / dt + slack);
+    lo = (int)fminf(fmaxf(flo, 0.f), 1.0e9f);
+    hi = (int)fminf(fmaxf(fhi, 0.f), 1.0e9f);
+    return lo <= hi;
+}
+
 template <bool BWD, bool FADE8>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
                                              const bool emit_all) {
@@ -362,16 +378,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             rtmin = fminf(rtmin, tn);
             rtmax = fmaxf(rtmax, tf);
         }
-        // lattice steps of this ray that can fall inside this primitive (+-1 step of slack; the strict
-        // inside test on the evaluated position decides, exactly as in the reference)
-        const float ta = fmaxf(tn, tmin), tb = fminf(tf, tmax + 1e-5f);
-        const bool some = hit && (ta <= tb);
+        // lattice steps of this ray that can fall inside this primitive
         int lo = 0x7fffffff, hi = -1;
-        if (some) {
-            const float flo = floorf((ta - tmin) / dt) - 1.f, fhi = floorf((tb - tmin) / dt) + 1.f;
-            lo = (int)fminf(fmaxf(flo, 0.f), 1.0e9f);
-            hi = (int)fminf(fmaxf(fhi, 0.f), 1.0e9f);
-        }
+        const bool some = hit && lane_step_range(tn, tf, tmin, tmax, dt, lo, hi);
+        if (!some) lo = 0x7fffffff, hi = -1;
         if (__ballot(some) != 0ull) {  // wave-uniform
             const int wlo = uni(wave_min(lo)), whi = uni(wave_max(hi));
             if (whi >= 65535) ranges_ok = false;
@@ -727,7 +737,8 @@ constexpr int kPrimBlock = 256;
 constexpr int kFixHiBits = 14;
 constexpr uint32_t kFixMaxSamples = 65536u;
 constexpr int kQueueCap = 512;      // rays per round: 8 entries x 64 lanes
-constexpr int kEntriesPerRound = 8;
+constexpr int kEntriesPerRound = 8;  // two per wave
+constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
 
 // G = max |grad_rayrgba|, Rmax = max |raysat| -> out[0], out[1] (float bits; non-negative floats order like uints)
 __global__ __launch_bounds__(256) void absmax2_kernel(const float4 *__restrict__ g4, size_t n4,
@@ -770,6 +781,7 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
     uint4 *s_q = reinterpret_cast<uint4 *>(s_lo + 4 * Vp);  // Vp % 4 == 0 keeps this 16-byte aligned
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
+    uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = lanemask_lt(lane);
@@ -854,48 +866,71 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
     for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
-        if (tid == 0) *s_qn = 0u;
+        if (tid < kLenBuckets) s_bucket[tid] = 0u;
         __syncthreads();
         // ---------------- phase 1: which rays of these packets cross the box, and over which steps ----------------
+        // Each wave owns up to two entries of the round; a live ray takes a ticket in the bucket of its step count
+        // (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the
+        // 64 rays a wave marches together have (nearly) the same number of steps.
         const uint32_t eend = min(cnt, ebase + (uint32_t)kEntriesPerRound);
-        for (uint32_t e = ebase + wave; e < eend; e += kPrimBlock / kWave) {
-            const uint2 ent = list[e];
-            const int tidx = (int)(ent.x >> 9);
-            const uint32_t slot = ent.x & 511u;
-            const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);
-            const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
-            const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-            const bool inimg = px < p.W && py < p.H;
-            const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
-            int slo = 1, shi = 0;
-            if (inimg) {
-                const f3 o = ld3(p.raypos + r * 3), d = ld3(p.raydir + r * 3);
-                const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
-                const int incs = (int)p.rayaux[r * 4 + 2];
-                // the same formulas the forward used for the packet range [elo, ehi] (the union of these over lanes)
-                const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
-                const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
-                const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
-                const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
-                const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
-                const float ta = fmaxf(tn, tt.x), tb = fminf(tf, tt.y + 1e-5f);
-                if (tn <= tf && ta <= tb) {
-                    slo = max((int)fminf(fmaxf(floorf((ta - tt.x) / dt) - 1.f, 0.f), 1.0e9f), max(elo, incs));
-                    shi = min((int)fminf(fmaxf(floorf((tb - tt.x) / dt) + 1.f, 0.f), 1.0e9f), ehi);
+        uint4 item[2];
+        uint32_t ticket[2];
+        bool live2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
+            live2[u] = false;
+            ticket[u] = 0u;
+            item[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < eend) {
+                const uint2 ent = list[e];
+                const int tidx = (int)(ent.x >> 9);
+                const uint32_t slot = ent.x & 511u;
+                const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);
+                const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
+                const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+                const bool inimg = px < p.W && py < p.H;
+                const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
+                int slo = 1, shi = 0;
+                if (inimg) {
+                    const f3 o = ld3(p.raypos + r * 3), d = ld3(p.raydir + r * 3);
+                    const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
+                    const int incs = (int)p.rayaux[r * 4 + 2];
+                    // the same formulas the forward used for the packet range [elo, ehi] (the union of these over lanes)
+                    const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
+                    const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
+                    const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
+                    const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+                    const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+                    int l0, h0;
+                    if (lane_step_range(tn, tf, tt.x, tt.y, dt, l0, h0)) {
+                        slo = max(l0, max(elo, incs));
+                        shi = min(h0, ehi);
+                    }
+                }
+                if (slo <= shi) {
+                    const int len = shi - slo + 1;
+                    live2[u] = true;
+                    item[u] = make_uint4((uint32_t)r, (uint32_t)slo | ((uint32_t)len << 16), slot, 0u);
+                    ticket[u] = atomicAdd(s_bucket + min(len, kLenBuckets) - 1, 1u);
                 }
             }
-            const bool live = slo <= shi;
-            const unsigned long long m = __ballot(live);
-            if (m != 0ull) {
-                uint32_t base = 0u;
-                if (lane == 0) base = atomicAdd(s_qn, (uint32_t)__popcll(m));
-                base = (uint32_t)uni((int)base);
-                if (live)
-                    s_q[base + (uint32_t)__popcll(m & lt)] =
-                        make_uint4((uint32_t)r, (uint32_t)slo | ((uint32_t)(shi - slo + 1) << 16), slot, 0u);
-            }
         }
+        __syncthreads();
+        if (tid == 0) {  // exclusive prefix over the buckets, longest rays first
+            uint32_t acc = 0u;
+            for (int bkt = kLenBuckets - 1; bkt >= 0; --bkt) {
+                const uint32_t c = s_bucket[bkt];
+                s_bucket[bkt] = acc;
+                acc += c;
+            }
+            *s_qn = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (live2[u]) s_q[s_bucket[min((int)(item[u].y >> 16), kLenBuckets) - 1] + ticket[u]] = item[u];
         __syncthreads();
         // ---------------- phase 2: the queued rays, split evenly over the 4 waves ----------------
         const int nq = (int)*s_qn;
@@ -1189,7 +1224,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
     const size_t Vp = (size_t)TD * ((size_t)TH * TW + 4);
     // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
-    const size_t lds = V * 16 + Vp * 32 + 512 * 16 + 64 * sizeof(float) + 16;
+    const size_t lds = V * 16 + Vp * 32 + 512 * 16 + 64 * sizeof(float) + 16 + 32 * 4;
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
     const bool prim_path = !norays && have_lists && lds <= 64 * 1024;
     const bool fade8 = fadeexp == 8.0f;
