@@ -770,7 +770,7 @@ __device__ __forceinline__ float fix_scale(float B) {
 }
 
 template <bool FADE8>
-__global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams p) {
+__global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchParams p) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int V = p.TD * p.TH * p.TW;
     const int gH = p.TW, gD = p.TH * p.TW + 4;  // gradient-array strides (words); x stride 1
@@ -961,6 +961,7 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
             }
             const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
             const int nsteps = uni(wave_max(len));
+            float ra0 = 0.f, ra1 = 0.f, ra2 = 0.f, rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
             for (int st = 0; st < nsteps; ++st) {
                 const int s = slo + st;
                 const float t = fmaf((float)s, dt, tmin);
@@ -1026,6 +1027,17 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
                     const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
                     f3 gy = ypow * gf;
                     dLs.w *= fade;
+#define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
+                    const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
+                                d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
+                                d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
+#undef MVP_DOT4
+                    gy.x += mx * (wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) + wy0 * wz1 * (d101 - d100) +
+                                  wy1 * wz1 * (d111 - d110));
+                    gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
+                                  wx1 * wz1 * (d111 - d101));
+                    gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
+                                  wx1 * wy1 * (d111 - d011));
                     // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
                     {
                         const float qx = dLs.x * s_rgb, qy = dLs.y * s_rgb, qz = dLs.z * s_rgb, qw = dLs.w * s_a;  // exact
@@ -1054,22 +1066,17 @@ __global__ __launch_bounds__(kPrimBlock) void bwd_prim_kernel(const MarchParams 
 #undef MVP_LSCATTER
 #undef MVP_FIX1
                     }
-#define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
-                    const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
-                                d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
-                                d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
-#undef MVP_DOT4
-                    gy.x += mx * (wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) + wy0 * wz1 * (d101 - d100) +
-                                  wy1 * wz1 * (d111 - d110));
-                    gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
-                                  wx1 * wz1 * (d111 - d101));
-                    gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
-                                  wx1 * wy1 * (d111 - d011));
-                    a0 += gy.x, a1 += gy.y, a2 += gy.z;
-                    c00 += xmt.x * gy.x, c01 += xmt.x * gy.y, c02 += xmt.x * gy.z;
-                    c10 += xmt.y * gy.x, c11 += xmt.y * gy.y, c12 += xmt.y * gy.z;
-                    c20 += xmt.z * gy.x, c21 += xmt.z * gy.y, c22 += xmt.z * gy.z;
+                    // xmt = (o - pos) + d * t is affine in t along this ray: keep sum(gy) and sum(t * gy) only
+                    ra0 += gy.x, ra1 += gy.y, ra2 += gy.z;
+                    rb0 = fmaf(t, gy.x, rb0), rb1 = fmaf(t, gy.y, rb1), rb2 = fmaf(t, gy.z, rb2);
                 }
+            }
+            {  // sum xmt_i * gy_j over this ray's samples = (o_i - pos_i) * sum(gy_j) + d_i * sum(t * gy_j)
+                const f3 om = o - q.pos;
+                a0 += ra0, a1 += ra1, a2 += ra2;
+                c00 += om.x * ra0 + d.x * rb0, c01 += om.x * ra1 + d.x * rb1, c02 += om.x * ra2 + d.x * rb2;
+                c10 += om.y * ra0 + d.y * rb0, c11 += om.y * ra1 + d.y * rb1, c12 += om.y * ra2 + d.y * rb2;
+                c20 += om.z * ra0 + d.z * rb0, c21 += om.z * ra1 + d.z * rb1, c22 += om.z * ra2 + d.z * rb2;
             }
         }
         __syncthreads();  // the queue is rewritten by the next round
