@@ -64,6 +64,7 @@ struct MarchParams {
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
     int total_packets;    // 8 * chunk * N
     int debug_force_dfs;  // tests: MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
+    int debug_stage;      // profiling only: MVP_DEBUG_STAGE=1 stop after traversal, 2 after the exact pass, 3 no sampling
 };
 
 constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than pl_cap packets
@@ -151,6 +152,51 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d)
 // One ray packet (8x8 pixels, one wave).  s_a: frontier ping, later packed step ranges (lo | hi << 16);
 // s_b: frontier pong / candidate list / final list (k | slot << 24); s_rec: SRT records of the first 64 candidates.
 // BWD instantiation = ray-centric fallback backward; emit_all: it owns every primitive (else only overflowed ones).
+// Forward sample of one slab at box coordinate y (strictly inside (-1,1)^3): fade (primsampler.h:48-51) times the
+// channels-last trilinear lookup (utils.h:414-468; base corner clamped so that all 8 corners are in bounds, which
+// gives the same value as the reference's zero-padded form).  Returns (r, g, b, alpha * fade).
+template <bool FADE8>
+__device__ __forceinline__ float4 sample_slab(const float *__restrict__ Tk, f3 y, int TD, int TH, int TW,
+                                              float fadescale, float fadeexp) {
+    float fade;
+    if (FADE8) {
+        const f3 y2 = y * y, y4 = y2 * y2;
+        fade = fast_exp(-fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+    } else {
+        fade = fast_exp(-fadescale * (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp) +
+                                      fast_pow(fabsf(y.z), fadeexp)));
+    }
+    const float ix = (y.x + 1.f) * 0.5f * (float)(TW - 1);
+    const float iy = (y.y + 1.f) * 0.5f * (float)(TH - 1);
+    const float iz = (y.z + 1.f) * 0.5f * (float)(TD - 1);
+    const int x0 = min((int)floorf(ix), TW - 2), y0 = min((int)floorf(iy), TH - 2), z0 = min((int)floorf(iz), TD - 2);
+    const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
+    const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+    const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+    const int sW = 4, sH = TW * 4, sD = TH * TW * 4;
+    const float *Tp = Tk + (size_t)z0 * sD + (size_t)y0 * sH + (size_t)x0 * sW;
+    const float4 c000 = *reinterpret_cast<const float4 *>(Tp);
+    const float4 c001 = *reinterpret_cast<const float4 *>(Tp + sW);
+    const float4 c010 = *reinterpret_cast<const float4 *>(Tp + sH);
+    const float4 c011 = *reinterpret_cast<const float4 *>(Tp + sH + sW);
+    const float4 c100 = *reinterpret_cast<const float4 *>(Tp + sD);
+    const float4 c101 = *reinterpret_cast<const float4 *>(Tp + sD + sW);
+    const float4 c110 = *reinterpret_cast<const float4 *>(Tp + sD + sH);
+    const float4 c111 = *reinterpret_cast<const float4 *>(Tp + sD + sH + sW);
+    const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0,
+                w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+    float4 v;
+    v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 + c101.x * w101 +
+          c110.x * w110 + c111.x * w111;
+    v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 + c101.y * w101 +
+          c110.y * w110 + c111.y * w111;
+    v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 + c101.z * w101 +
+          c110.z * w110 + c111.z * w111;
+    v.w = (c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 + c101.w * w101 +
+           c110.w * w110 + c111.w * w111) * fade;
+    return v;
+}
+
 // Lattice steps s (t_s = tmin + s*dt) of one ray that can fall strictly inside a box whose slab interval is
 // [tn, tf] (utils.h:747-753), clipped to the ray's [tmin, tmax + 1e-5).  The strict inside test on the evaluated
 // position decides membership exactly as in the reference; this range only has to contain every step that test
@@ -359,6 +405,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         }
     }
 
+    if (p.debug_stage == 1) ncand = 0;
     // ---------------- exact per-ray leaf test (utils.h:744-761), lanes over rays ----------------
     float rtmin = INFINITY, rtmax = -INFINITY;
     bool ranges_ok = true;  // false when a step index does not fit the packed 16-bit range
@@ -399,6 +446,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
     __syncthreads();
 
+    if (p.debug_stage == 2) nh = 0;
     // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
     if (!BWD && p.pl_count != nullptr && nh > 0) {
         uint32_t *flags = p.pl_count + (size_t)p.N * K;
@@ -478,6 +526,54 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 }
                 unsigned long long m = __ballot(on);
                 anyslot = anyslot || (m != 0ull);
+                if (!BWD) {
+                    // Forward: (A) every active slot's inside test with the record broadcast from LDS -> per-lane
+                    // bitmask of the slots this ray is inside at this step; (B) every lane then consumes ITS OWN
+                    // slots in ascending list order, all lanes sampling at once (records gathered per lane).  On
+                    // head-like scenes the boxes active at one step cover mostly disjoint parts of the packet, so
+                    // (B) runs ~overlap-depth rounds instead of one round per active slot.
+                    unsigned long long mine = 0ull;
+                    while (m) {
+                        const int bit = __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        const int ent = uni(s_b[ch * kWave + bit]);
+                        const int slot = (ent >> 24) & 0xff;
+                        const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot)
+                                                         : rec_from_global(pp, pr, ps, ent & 0xffffff);
+                        const f3 y = rot_rows(q, x - q.pos) * q.scale;
+                        const bool inside = inrange && !sat && y.x > -1.f && y.x < 1.f && y.y > -1.f && y.y < 1.f &&
+                                            y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
+                        if (inside) mine |= 1ull << bit;
+                    }
+                    if (p.debug_stage == 3) mine = 0ull;
+                    while (__ballot(mine != 0ull) != 0ull) {
+                        if (mine != 0ull) {
+                            const int bit = __ffsll((long long)mine) - 1;
+                            mine &= mine - 1ull;
+                            const int ent = s_b[ch * kWave + bit];
+                            const int k = ent & 0xffffff, slot = (ent >> 24) & 0xff;
+                            const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
+                            const f3 y = rot_rows(q, x - q.pos) * q.scale;
+                            const float4 v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale,
+                                                                p.fadeexp);
+                            // ---- primaccum.h:63-79 ----
+                            const float newalpha = rgba.w + v.w * dt;
+                            const float contrib = fminf(newalpha, 1.f) - rgba.w;
+                            rgba.x += v.x * contrib;
+                            rgba.y += v.y * contrib;
+                            rgba.z += v.z * contrib;
+                            rgba.w += contrib;
+                            if (newalpha >= 1.f) {
+                                raysat = mk3(v.x, v.y, v.z);
+                                sat = true;
+                                satkey = ((uint32_t)s << 9) | (uint32_t)(ch * kWave + bit);
+                                wbefore = rgba.w - contrib;
+                                mine = 0ull;  // saturated: nothing after this sample is evaluated
+                            }
+                        }
+                    }
+                    continue;
+                }
                 while (m) {
                     const int bit = __ffsll((long long)m) - 1;
                     m &= m - 1ull;
@@ -1149,6 +1245,8 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     {
         const char *e = getenv("MVP_DEBUG_FORCE_DFS");
         p.debug_force_dfs = (e && e[0] == '1') ? 1 : 0;
+        const char *g = getenv("MVP_DEBUG_STAGE");
+        p.debug_stage = g ? atoi(g) : 0;
     }
     (void)bwd;
     return MVP_OK;

@@ -31,30 +31,60 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
+// Wave64 reductions without LDS traffic: a 4-step DPP butterfly reduces each row of 16 lanes (every lane of the row
+// ends up with the row result), then the four row results are read with v_readlane and combined.  A ds_bpermute
+// butterfly (what __shfl_xor compiles to) costs 6 dependent LDS round trips per reduction; the exact-test loop of
+// the march does two reductions per candidate primitive.
+//   DPP controls (gfx9): quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+#define MVP_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ float dpp_f(float v, int which) {
+    const int i = __float_as_int(v);
+    int r;
+    switch (which) {
+        case 0: r = MVP_DPP_I(i, 0xB1); break;
+        case 1: r = MVP_DPP_I(i, 0x4E); break;
+        case 2: r = MVP_DPP_I(i, 0x141); break;
+        default: r = MVP_DPP_I(i, 0x140); break;
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ int dpp_i(int i, int which) {
+    switch (which) {
+        case 0: return MVP_DPP_I(i, 0xB1);
+        case 1: return MVP_DPP_I(i, 0x4E);
+        case 2: return MVP_DPP_I(i, 0x141);
+        default: return MVP_DPP_I(i, 0x140);
+    }
+}
+#undef MVP_DPP_I
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int w = 0; w < 4; ++w) v = fminf(v, dpp_f(v, w));
+    return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int w = 0; w < 4; ++w) v = fmaxf(v, dpp_f(v, w));
+    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
 }
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int w = 0; w < 4; ++w) v = min(v, dpp_i(v, w));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int w = 0; w < 4; ++w) v = max(v, dpp_i(v, w));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int w = 0; w < 4; ++w) v += dpp_f(v, w);
+    return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
 }
 // make a value the compiler cannot prove uniform live in an SGPR
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
