@@ -803,7 +803,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
 //   LDS: [V] float4 template slab | [4][Vp] int32 gradient "hi" | [4][Vp] uint32 gradient "lo" |
-//        ray queue (512 x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + 4, see below).
+//        [4][Vp] float drain target | ray queue (512 x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + 4, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
 //             COMPACTED into the LDS queue (ballot + popcount prefix inside the wave, one LDS integer atomic per
@@ -823,8 +823,10 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // accumulators per slab float).  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed
 // bound B of any single contribution (|value * 2^e| < 2^14), so sums of up to 65536 contributions cannot
 // overflow; the resolution is 2^-30 * B.  Sums are exact integers => the slab gradient is bit-reproducible run
-// to run (the fp32-atomic formulation is not).  Primitives whose sample budget exceeds 65536, or with a
-// non-finite bound, are handed to the ray-centric kernel through the same flag the forward uses for list overflow.
+// to run (the fp32-atomic formulation is not).  The exact number of samples each round can add is counted while
+// the rays are queued; before the running total could pass 65536 the integer sums are drained into a float array
+// in LDS (plain adds by the owning threads) and restart from zero, so any number of samples per primitive is fine.
+// Primitives with a non-finite bound are handed to the ray-centric kernel through the forward's overflow flag.
 // The gradient arrays use a z stride of TH*TW + 4 words: the rays of a batch sit on a sheet of cells that is
 // ~5 x 5 in two box axes and straddles two layers of the third; with the natural stride (a multiple of 32 banks)
 // the two layers would collide bank for bank.
@@ -874,7 +876,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     float4 *s_T = smem4;
     int *s_hi = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar
     uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_hi + 4 * Vp);
-    uint4 *s_q = reinterpret_cast<uint4 *>(s_lo + 4 * Vp);  // Vp % 4 == 0 keeps this 16-byte aligned
+    float *s_gf = reinterpret_cast<float *>(s_lo + 4 * Vp);  // [4][Vp] float: receives the integer sums whenever the
+                                                             // per-slab sample count since the last drain nears 65536
+    uint4 *s_q = reinterpret_cast<uint4 *>(s_gf + 4 * Vp);  // Vp % 4 == 0 keeps this 16-byte aligned
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
@@ -897,9 +901,8 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
 
-    // ---- stage the slab, its max |rgb|, and this primitive's sample budget ----
+    // ---- stage the slab and its max |rgb| ----
     float tmax = 0.f;
-    uint32_t budget = 0u;
     if (!dead && cnt > 0u) {
         const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
         for (int v = tid; v < V; v += kPrimBlock) {
@@ -910,30 +913,21 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         for (int v = tid; v < 4 * Vp; v += kPrimBlock) {
             s_hi[v] = 0;
             s_lo[v] = 0u;
-        }
-        for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
-            const uint32_t rg = list[e].y;
-            budget += ((rg >> 16) - (rg & 0xffffu) + 1u) * 64u;
+            s_gf[v] = 0.f;
         }
         tmax = wave_max(tmax);
-        budget = (uint32_t)wave_sum((float)min(budget, 1u << 22));  // exact below 2^24; only compared to 2^16
-        if (lane == 0) {
-            s_red[wave] = tmax;
-            s_red[4 + wave] = (float)budget;
-        }
+        if (lane == 0) s_red[wave] = tmax;
     }
     __syncthreads();
     float s_rgb = 0.f, s_a = 0.f;
     if (!dead && cnt > 0u) {
         tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        const float fb = s_red[4] + s_red[5] + s_red[6] + s_red[7];
         const float G = __uint_as_float(tail[1]), Rmax = __uint_as_float(tail[2]);
         // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
         const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
         if (G == 0.f) {
             s_rgb = s_a = -1.f;  // all-zero upstream gradient: outputs are zero
-        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f) ||
-                   fb > (float)kFixMaxSamples) {
+        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f)) {
             dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
             if (tid == 0) {
                 p.pl_count[pk] = 0xffffffffu;
@@ -961,8 +955,11 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
+    if (tid == 0) s_qn[2] = 0u;
+    uint32_t pending = 0u;  // samples accumulated into the integer arrays since the last drain (workgroup-uniform)
     for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
         if (tid < kLenBuckets) s_bucket[tid] = 0u;
+        if (tid == 0) s_qn[1] = 0u;
         __syncthreads();
         // ---------------- phase 1: which rays of these packets cross the box, and over which steps ----------------
         // Each wave owns up to two entries of the round; a live ray takes a ticket in the bucket of its step count
@@ -972,6 +969,8 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         uint4 item[2];
         uint32_t ticket[2];
         bool live2[2];
+        bool toolong = false;
+        uint32_t mylen = 0u;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
@@ -1006,14 +1005,34 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     }
                 }
                 if (slo <= shi) {
+                    // at most 127 steps per queued item, so that one round adds <= 512 * 127 < 65536 samples; a box
+                    // that is deeper than that along some ray is handed to the ray-centric kernel (flagged below)
                     const int len = shi - slo + 1;
+                    if (len > 127) toolong = true;
                     live2[u] = true;
                     item[u] = make_uint4((uint32_t)r, (uint32_t)slo | ((uint32_t)len << 16), slot, 0u);
                     ticket[u] = atomicAdd(s_bucket + min(len, kLenBuckets) - 1, 1u);
+                    mylen += (uint32_t)len;
                 }
             }
         }
+        if (__ballot(toolong) != 0ull && lane == 0) atomicOr(s_qn + 2, 1u);
+        {  // exact number of samples this round can add: one LDS atomic per wave (values < 2^24: exact in float)
+            const float wl = wave_sum((float)mylen);
+            if (lane == 0 && wl > 0.f) atomicAdd(s_qn + 1, (uint32_t)wl);
+        }
         __syncthreads();
+        if (s_qn[2] != 0u) {  // a ray crosses this box over more than 127 steps: not this kernel's case
+            if (tid == 0) {
+                p.pl_count[pk] = 0xffffffffu;
+                atomicOr(tail, kFlagListOverflow);
+            }
+            for (int v = tid; v < V; v += kPrimBlock) gT4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < 9) p.grad_primrot[pk * 9 + tid] = 0.f;
+            if (tid < 3) p.grad_primscale[pk * 3 + tid] = 0.f;
+            if (tid < 3) p.grad_primpos[pk * 3 + tid] = 0.f;
+            return;
+        }
         if (tid == 0) {  // exclusive prefix over the buckets, longest rays first
             uint32_t acc = 0u;
             for (int bkt = kLenBuckets - 1; bkt >= 0; --bkt) {
@@ -1028,6 +1047,20 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         for (int u = 0; u < 2; ++u)
             if (live2[u]) s_q[s_bucket[min((int)(item[u].y >> 16), kLenBuckets) - 1] + ticket[u]] = item[u];
         __syncthreads();
+        // ---------------- drain the integer accumulators before they could overflow ----------------
+        const uint32_t round_samples = s_qn[1];
+        if (pending + round_samples > kFixMaxSamples) {
+            const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
+            for (int v = tid; v < 4 * Vp; v += kPrimBlock) {
+                const float inv = v < 3 * Vp ? i_rgb : i_a;
+                s_gf[v] += ((float)s_hi[v] * 65536.f + (float)s_lo[v]) * inv;
+                s_hi[v] = 0;
+                s_lo[v] = 0u;
+            }
+            pending = 0u;
+            __syncthreads();
+        }
+        pending += round_samples;  // a single round holds <= 512 rays x 65535 steps; see the guard below
         // ---------------- phase 2: the queued rays, split evenly over the 4 waves ----------------
         const int nq = (int)*s_qn;
         const int per = min(kWave, (nq + 3) >> 2);
@@ -1193,10 +1226,10 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
-            g.x = ((float)s_hi[gv] * 65536.f + (float)s_lo[gv]) * i_rgb;
-            g.y = ((float)s_hi[Vp + gv] * 65536.f + (float)s_lo[Vp + gv]) * i_rgb;
-            g.z = ((float)s_hi[2 * Vp + gv] * 65536.f + (float)s_lo[2 * Vp + gv]) * i_rgb;
-            g.w = ((float)s_hi[3 * Vp + gv] * 65536.f + (float)s_lo[3 * Vp + gv]) * i_a;
+            g.x = s_gf[gv] + ((float)s_hi[gv] * 65536.f + (float)s_lo[gv]) * i_rgb;
+            g.y = s_gf[Vp + gv] + ((float)s_hi[Vp + gv] * 65536.f + (float)s_lo[Vp + gv]) * i_rgb;
+            g.z = s_gf[2 * Vp + gv] + ((float)s_hi[2 * Vp + gv] * 65536.f + (float)s_lo[2 * Vp + gv]) * i_rgb;
+            g.w = s_gf[3 * Vp + gv] + ((float)s_hi[3 * Vp + gv] * 65536.f + (float)s_lo[3 * Vp + gv]) * i_a;
             gT4[v] = g;
         }
     }
@@ -1329,7 +1362,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
     const size_t Vp = (size_t)TD * ((size_t)TH * TW + 4);
     // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
-    const size_t lds = V * 16 + Vp * 32 + 512 * 16 + 64 * sizeof(float) + 16 + 32 * 4;
+    const size_t lds = V * 16 + Vp * 48 + 512 * 16 + 64 * sizeof(float) + 16 + 32 * 4;
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
     const bool prim_path = !norays && have_lists && lds <= 64 * 1024;
     const bool fade8 = fadeexp == 8.0f;

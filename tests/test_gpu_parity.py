@@ -117,6 +117,7 @@ SCENES = [
     (1, 33, 65, 1, 30.0, 8),      # a single primitive (root is a leaf)
     (1, 48, 48, 300, 5.0, 4),     # 4^3 slabs, K not a power of two
     (1, 24, 24, 2, 30.0, 8),
+    (1, 256, 256, 128, 3.0, 8),   # ~160k samples per primitive: the integer LDS accumulators are drained several times
 ]
 
 
