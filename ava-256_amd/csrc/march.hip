@@ -1065,8 +1065,11 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         const int nq = (int)*s_qn;
         const int per = min(kWave, (nq + 3) >> 2);
         for (int qb = wave * per; qb < nq; qb += 4 * per) {
-            const bool have = lane < per && qb + lane < nq;
-            const uint4 it = have ? s_q[qb + lane] : make_uint4(0u, 0u, 0u, 0u);
+            // queue neighbours are usually neighbouring pixels, i.e. rays in the same slab cell: put them in DIFFERENT
+            // 32-lane halves so that their LDS atomics to the same address do not meet in one pass
+            const int ql = ((lane & 31) << 1) | (lane >> 5);
+            const bool have = ql < per && qb + ql < nq;
+            const uint4 it = have ? s_q[qb + ql] : make_uint4(0u, 0u, 0u, 0u);
             const size_t r = it.x;
             const int slo = (int)(it.y & 0xffffu), len = have ? (int)(it.y >> 16) : 0;
             const uint32_t slot = it.z;
