@@ -283,11 +283,26 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             const float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
             if (!packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y)) ncur = 0;
         }
+        // Coarse pre-cull of the implicit level: its nodes are grouped 32 per ancestor 5 levels up (<= 32 ancestors,
+        // one lane each); groups whose ancestor fails the packet test are skipped without touching their boxes.
+        unsigned anc_pass = 0xffffffffu;
+        if (ncur > 0 && ds >= 5) {
+            const int nanc = 1 << (ds - 5);
+            bool ok = false;
+            if (lane < nanc) {
+                const float2 *ap = reinterpret_cast<const float2 *>(A + (size_t)(nanc - 1 + lane) * 6);
+                const float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+                ok = packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
+            }
+            anc_pass = (unsigned)__ballot(ok);
+            if (anc_pass == 0u) ncur = 0;
+        }
         for (int dep = ds; ncur > 0; ++dep) {
             int nnext = 0;
             for (int base = 0; base < ncur; base += kWave) {
                 const int idx = base + lane;
-                const bool have = idx < ncur;
+                if (dep == ds && ((anc_pass >> (base >> 5)) & 3u) == 0u) continue;  // both ancestor groups culled
+                const bool have = idx < ncur && (dep != ds || ((anc_pass >> (idx >> 5)) & 1u) != 0u);
                 const int e = !have ? 0 : (dep == ds ? first + idx : cur[idx]);
                 const bool tested_leaf = e < 0;  // ~node: a leaf that already passed, carried to keep order
                 const int g = tested_leaf ? ~e : e;
@@ -507,6 +522,9 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         }
         const int nchunks = (nh + kWave - 1) / kWave;
         bool sat = false;
+        // list slot `lane` of chunk 0 (every packet of a head-like scene fits in it): range and entry in registers
+        const int rg0 = lane < nh ? s_a[lane] : 0;
+        const int ent0 = lane < nh ? s_b[lane] : 0;
 
         while (s <= s_last) {
             if (__ballot(has && !sat) == 0ull) break;  // every ray saturated (subset_kernel.h:76)
@@ -519,7 +537,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 const int j = ch * kWave + lane;
                 bool on = false;
                 if (j < nh) {
-                    const int rg = s_a[j];
+                    const int rg = ch == 0 ? rg0 : s_a[j];
                     const int lo = rg & 0xffff, hi = (rg >> 16) & 0xffff;
                     on = !ranges_ok || (lo <= s && s <= hi);
                     if (lo > s) nextlo = min(nextlo, lo);
@@ -533,10 +551,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                     // head-like scenes the boxes active at one step cover mostly disjoint parts of the packet, so
                     // (B) runs ~overlap-depth rounds instead of one round per active slot.
                     unsigned long long mine = 0ull;
-                    while (m) {
+                    while (m) {  // list entries of chunk 0 come from registers via v_readlane (no LDS round trip)
                         const int bit = __ffsll((long long)m) - 1;
                         m &= m - 1ull;
-                        const int ent = uni(s_b[ch * kWave + bit]);
+                        const int ent = ch == 0 ? __builtin_amdgcn_readlane(ent0, bit) : uni(s_b[ch * kWave + bit]);
                         const int slot = (ent >> 24) & 0xff;
                         const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot)
                                                          : rec_from_global(pp, pr, ps, ent & 0xffffff);
