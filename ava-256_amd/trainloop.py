@@ -1,0 +1,156 @@
+"""Training-loop counterpart for the raymarch hot path.
+
+The reference's loop is `ddp-train.py:362-445`: forward through the autoencoder, L1 image loss (+ geometry / KL terms
+that belong to the conv encoders), `primvolsum` regulariser, `loss.backward()`, per-parameter NaN/Inf -> 0,
+`clip_grad_norm_(1.0)`, Adam step, StepLR; one process per GPU under `DistributedDataParallel`, only parameter
+gradients cross GPUs.  None of the reference's Python travels to the GPU box and its conv encoders/decoders are out of
+scope for this build, so this module keeps the LOOP faithful and puts a small stand-in where
+the conv decoder would be:
+
+  SlabDecoderStandIn   emits the same `decout` dict a DecoderAssembler emits (models/decoders/assembler.py:263-269:
+                       template [B,K,8,8,8,4] = cat(relu(rgb*25+100), relu(alpha)), primpos, primrot, primscale) from
+                       per-primitive parameters and a per-frame code; ~2k parameters per primitive, so K=16384 gives
+                       a 134 MB gradient all-reduce -- the same order as ava-256's 187.5 MB.
+  RaymarchTrainModel   decoder -> compute_raydirs -> Raymarcher -> matting, like Autoencoder.decode
+                       (models/autoencoder.py:240-265).
+  Trainer              the loop body with the reference's semantics and hyper-parameters (configs/config.yaml:9-21).
+
+What is measured with it (bench.py --mode train) is therefore "iterations/s of the raymarch training path with a
+stand-in decoder", not ava-256's full 46.9 M-parameter model; DESIGN.md says so wherever the number appears.
+"""
+import math
+from typing import Callable, Dict, Optional
+
+import torch
+from torch import nn
+
+from .raydirs import compute_raydirs
+from .raymarcher import Raymarcher
+from .scene import make_primitives, rodrigues
+
+
+def mean_ell_1(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """losses.py:12-14 of the reference."""
+    return (pred - gt).abs().mean()
+
+
+class SlabDecoderStandIn(nn.Module):
+    def __init__(self, K: int, slab: int = 8, code_dim: int = 16, seed: int = 0):
+        super().__init__()
+        base = make_primitives(1, K, device="cpu", seed=seed, slab=slab)
+        self.K, self.slab = K, slab
+        self.register_buffer("base_pos", base["primpos"][0].clone())
+        self.register_buffer("base_rot", base["primrot"][0].clone())
+        self.register_buffer("base_scale", base["primscale"][0].clone())
+        g = torch.Generator().manual_seed(seed + 17)
+        # pre-activation slabs with the random-init statistics of the real decoder heads
+        self.rgb = nn.Parameter(torch.randn(K, slab, slab, slab, 3, generator=g))
+        self.alpha = nn.Parameter(0.5 + 0.1 * torch.randn(K, slab, slab, slab, 1, generator=g))
+        self.pos_delta = nn.Parameter(torch.zeros(K, 3))
+        self.rotvec = nn.Parameter(torch.zeros(K, 3))
+        self.logscale = nn.Parameter(torch.zeros(K, 3))
+        self.gain = nn.Linear(code_dim, K)  # per-frame, per-primitive brightness (view / expression conditioning)
+        with torch.no_grad():  # seeded like everything else: identical on every rank and in every process
+            self.gain.weight.copy_(0.01 * torch.randn(K, code_dim, generator=g))
+            self.gain.bias.zero_()
+
+    def forward(self, code: torch.Tensor) -> Dict[str, torch.Tensor]:
+        B = code.shape[0]
+        gain = 1.0 + 0.1 * torch.tanh(self.gain(code))                      # [B,K]
+        rgb = torch.relu(self.rgb * 25.0 + 100.0)                            # assembler.py:261
+        alpha = torch.relu(self.alpha)
+        template = torch.cat([rgb[None] * gain[:, :, None, None, None, None],
+                              alpha[None].expand(B, -1, -1, -1, -1, -1)], dim=-1).contiguous()
+        primpos = (self.base_pos + 0.01 * self.pos_delta)[None].expand(B, -1, -1).contiguous()
+        primrot = torch.matmul(self.base_rot, rodrigues(0.1 * self.rotvec))[None].expand(B, -1, -1, -1).contiguous()
+        primscale = (self.base_scale * torch.exp(0.1 * self.logscale))[None].expand(B, -1, -1).contiguous()
+        return {"template": template, "primpos": primpos, "primrot": primrot, "primscale": primscale}
+
+
+class RaymarchTrainModel(nn.Module):
+    """decoder -> rays -> raymarch -> matting (black background), the tail of Autoencoder.decode."""
+
+    def __init__(self, decoder: nn.Module, volradius: float = 256.0, dt: float = 1.0,
+                 renderer: Optional[Callable] = None):
+        super().__init__()
+        self.decoder = decoder
+        self.raymarcher = Raymarcher(volradius, dt)
+        self._renderer = renderer  # CPU tests inject a pure-torch stand-in; None = the gfx950 kernels
+
+    def forward(self, camrot, campos, focal, princpt, pixelcoords, code):
+        decout = self.decoder(code)
+        if self._renderer is not None:
+            rayrgb, rayalpha = self._renderer(camrot, campos, focal, princpt, pixelcoords, decout)
+        else:
+            raypos, raydir, tminmax = compute_raydirs(campos, camrot, focal, princpt, pixelcoords,
+                                                      self.raymarcher.volume_radius)
+            rayrgb, rayalpha, _, _ = self.raymarcher(raypos, raydir, tminmax, decout)
+        return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"]}
+
+
+class Trainer:
+    """One optimisation step with the reference's semantics (ddp-train.py:404-442)."""
+
+    def __init__(self, model: nn.Module, lr: float = 2.0e-4, lr_scheduler_iter: int = 10_000, gamma: float = 1.4,
+                 clip: float = 1.0, loss_weights: Optional[Dict[str, float]] = None, ddp: bool = False,
+                 device_ids=None, bucket_cap_mb: int = 256):
+        self.raw_model = model
+        if ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            # gradients only; no per-forward buffer broadcast (the reference's default re-broadcasts ~115 MB of
+            # buffers every iteration) and one flat bucket sized for point-to-point xGMI
+            model = DDP(model, device_ids=device_ids, broadcast_buffers=False, gradient_as_bucket_view=True,
+                        bucket_cap_mb=bucket_cap_mb)
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.optim = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999))
+        self.sched = torch.optim.lr_scheduler.StepLR(self.optim, step_size=lr_scheduler_iter, gamma=gamma)
+        self.clip = clip
+        self.loss_weights = loss_weights or {"irgbl1": 1.0, "primvolsum": 0.01}  # configs/config.yaml:17-21
+        self.iternum = 0
+
+    def losses(self, output, batch):
+        out = {}
+        if "irgbl1" in self.loss_weights:
+            out["irgbl1"] = mean_ell_1(output["irgbrec"], batch["image"])
+        if "primvolsum" in self.loss_weights:  # ddp-train.py:413-415
+            out["primvolsum"] = torch.sum(torch.prod(1.0 / output["primscale"], dim=-1), dim=-1)
+        return out
+
+    def step(self, batch: Dict[str, torch.Tensor]):
+        output = self.model(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
+                            batch["code"])
+        losses = self.losses(output, batch)
+        loss = sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
+        self.optim.zero_grad(set_to_none=False)
+        loss.backward()
+        # NaN / Inf -> 0 in every gradient (ddp-train.py:436-439 does two masked assignments per tensor, ~600 host
+        # syncs per iteration on ava-256; nan_to_num_ is the same mapping without the syncs)
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
+        torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        self.optim.step()
+        self.sched.step()
+        self.iternum += 1
+        return loss.detach(), {k: v.detach().mean() for k, v in losses.items()}
+
+
+@torch.no_grad()
+def make_training_batch(N, H, W, K, device, seed=1112, code_dim=16, target_decoder: Optional[nn.Module] = None):
+    """Synthetic batch with the keys of the reference's data contract that this path uses:
+    cameras, pixel grid, a per-frame code and target images.  Targets are renders of a differently-seeded stand-in
+    decoder, so the optimisation has something real to fit."""
+    from .scene import make_cameras, pixel_grid
+    cams = make_cameras(N, H, W, device=device, seed=seed)
+    g = torch.Generator(device=device).manual_seed(seed + 5)
+    batch = {k: cams[k] for k in ("camrot", "campos", "focal", "princpt")}
+    batch["pixelcoords"] = pixel_grid(N, H, W, device=device)
+    batch["code"] = torch.randn(N, code_dim, device=device, generator=g)
+    if target_decoder is not None:
+        tm = RaymarchTrainModel(target_decoder.to(device))
+        batch["image"] = tm(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
+                            batch["code"])["irgbrec"].clone()
+    else:
+        batch["image"] = torch.zeros(N, 3, H, W, device=device)
+    return batch, cams["volradius"]

@@ -74,6 +74,57 @@ def cpu_baseline(N, H, W, K, slab, budget_s=20.0):
                 reps, H, W, K, tt)}
 
 
+def train_mode(args, rank, local_rank, world, dev, dist):
+    """Reference-shaped training iterations (ava-256_amd/trainloop.py): stand-in decoder -> rays -> march fwd/bwd ->
+    L1 + primvolsum -> NaN mask -> clip -> Adam, DDP all-reduce of parameter gradients when world > 1."""
+    from ava256_amd import _hooks as mm
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer, make_training_batch
+    N, H, W, K, slab = WORKLOADS[args.workload]
+    batch, volradius = make_training_batch(N, H, W, K, dev, seed=1112 + rank,
+                                           target_decoder=SlabDecoderStandIn(K, slab, seed=9))
+    model = RaymarchTrainModel(SlabDecoderStandIn(K, slab, seed=1), volradius).to(dev)
+    nparams = sum(p.numel() for p in model.parameters())
+    tr = Trainer(model, ddp=world > 1, device_ids=[local_rank] if world > 1 else None)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(batch)
+    sync()
+    events = []
+    mm.set_event_sink(events)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    mm.set_event_sink(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kt = {}
+    for name, a, b in events:
+        kt.setdefault(name, []).append(a.elapsed_time(b))
+    kavg = {k: sum(v) / len(v) for k, v in kt.items()}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",
+            "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d frames/GPU, %dx%d, K=%d, %d^3 slabs" % (args.workload, N, H, W, K, slab),
+                       "parallelism": "DDP over %d rank(s), gradients only, one %0.1f MB bucket" % (world, nparams * 4e-6)},
+            "frames_per_s": N * world * args.steps / elapsed, "rays_per_s": N * H * W * world * args.steps / elapsed,
+            "allreduce_mb": nparams * 4e-6, "kernel_ms": kavg, "final_loss": float(loss)}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +133,9 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--alpha-gain", type=float, default=1.0, help="1.0 = random-init opacity (nothing saturates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="march", choices=["march", "train"],
+                    help="march (default, the contract metric): the raymarch hot path; train: the reference-shaped "
+                         "optimisation loop (stand-in decoder, DDP gradient all-reduce over RCCL) -> iterations/s")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,6 +154,10 @@ def main():
     import ava256_amd as ops
     from ava256_amd import _hooks as mm
     from ava256_amd.scene import make_scene
+
+    if args.mode == "train":
+        train_mode(args, rank, local_rank, world, dev, dist)
+        return
 
     N, H, W, K, slab = WORKLOADS[args.workload]
     s = make_scene(N, H, W, K, device=dev, seed=1112 + rank, alpha_gain=args.alpha_gain, slab=slab)

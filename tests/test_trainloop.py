@@ -1,0 +1,143 @@
+"""Training-loop counterpart (ava-256_amd/trainloop.py): loop semantics on CPU with an injected pure-torch renderer
+(no oracle, no kernels), the 2-rank gloo DDP path, and -- on the GPU -- a real optimisation through the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def fake_renderer(camrot, campos, focal, princpt, pixelcoords, decout):
+    """Differentiable stand-in for rays+raymarch on CPU: every decout tensor influences the image."""
+    B, H, W = pixelcoords.shape[:3]
+    t = decout["template"]
+    rgb = t[..., :3].mean(dim=(1, 2, 3, 4)) * (1.0 + decout["primpos"].mean(dim=(1, 2)))[:, None]      # [B,3]
+    a = torch.sigmoid(t[..., 3].mean(dim=(1, 2, 3, 4)) + decout["primrot"].mean(dim=(1, 2, 3)))         # [B]
+    img = rgb[:, :, None, None] * (pixelcoords[..., 0] / W + 1.0)[:, None]
+    return img * a[:, None, None, None], a[:, None, None, None].expand(B, 1, H, W)
+
+
+def _batch(N, H, W, seed, code_dim=16):
+    from ava256_amd.trainloop import make_training_batch
+    b, _ = make_training_batch(N, H, W, 8, "cpu", seed=seed, code_dim=code_dim)
+    g = torch.Generator().manual_seed(seed)
+    b["image"] = 50.0 + 10.0 * torch.randn(N, 3, H, W, generator=g)
+    return b
+
+
+def test_loop_semantics_cpu():
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer, mean_ell_1
+    torch.manual_seed(0)
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer)
+    tr = Trainer(model, lr=2e-4, lr_scheduler_iter=2, gamma=1.4, clip=1.0)
+    assert isinstance(tr.optim, torch.optim.Adam) and tr.optim.defaults["betas"] == (0.9, 0.999)
+    assert tr.loss_weights == {"irgbl1": 1.0, "primvolsum": 0.01}            # configs/config.yaml:17-21
+    b = _batch(3, 8, 8, 0)
+    out = model(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], b["code"])
+    ref = 1.0 * mean_ell_1(out["irgbrec"], b["image"]) + 0.01 * torch.mean(
+        torch.sum(torch.prod(1.0 / out["primscale"], dim=-1), dim=-1))      # ddp-train.py:404-430
+    loss, parts = tr.step(b)
+    assert torch.allclose(loss, ref.detach(), rtol=1e-6)
+    # StepLR(step_size=2, gamma=1.4): lr after 2 steps = 2e-4 * 1.4
+    tr.step(b)
+    assert abs(tr.optim.param_groups[0]["lr"] - 2e-4 * 1.4) < 1e-12
+    # gradient clipping: total norm after the step's clip is <= clip (checked on a fresh backward)
+    tr.optim.zero_grad()
+    out = model(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], b["code"])
+    (1000.0 * mean_ell_1(out["irgbrec"], b["image"])).backward()
+    torch.nn.utils.clip_grad_norm_(tr.params, 1.0)
+    tot = torch.sqrt(sum((p.grad ** 2).sum() for p in tr.params if p.grad is not None))
+    assert tot <= 1.0 + 1e-4
+
+
+def test_nan_and_inf_gradients_are_zeroed():
+    """ddp-train.py:436-439: NaN/Inf gradient entries become 0 before clipping and the optimiser step."""
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer)
+    tr = Trainer(model)
+    p = model.decoder.pos_delta
+    before = p.detach().clone()
+    h = p.register_hook(lambda g: torch.full_like(g, float("nan")))
+    h2 = model.decoder.logscale.register_hook(lambda g: torch.full_like(g, float("inf")))
+    tr.step(_batch(2, 8, 8, 1))
+    h.remove(), h2.remove()
+    for q in tr.params:
+        assert torch.isfinite(q).all()
+    assert torch.equal(p.detach(), before)          # zero gradient -> Adam leaves the parameter where it was
+    assert any(not torch.equal(q.detach(), q0) for q, q0 in [(model.decoder.rgb, torch.zeros_like(model.decoder.rgb))])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer
+    from test_trainloop import _batch, fake_renderer
+    # float64: the fake renderer's gradients are sums of +-1/numel terms that cancel; in float32 their value depends on
+    # the thread-level summation order by ~1e-3, which would mask what this test is about
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer).double()
+    tr = Trainer(model, ddp=True)
+    full = {k: v.double() for k, v in _batch(4, 8, 8, 7).items()}
+    shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    tr.step(shard)
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    for _ in range(2):
+        tr.step(shard)
+    torch.save({"state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "grads": grads},
+               os.path.join(outdir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_match_single_process(tmp_path):
+    """Only parameter gradients cross ranks; with equal shards the 2-rank result equals one process on the full batch
+    (mean of shard gradients = gradient of the mean loss)."""
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), "r0.pt"))
+    b = torch.load(os.path.join(str(tmp_path), "r1.pt"))
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), k       # ranks stay in lock-step
+    # first-step gradients (after all-reduce, NaN masking and clipping) equal the single-process ones.  Parameters
+    # after several Adam steps are not compared: Adam turns round-off-sized gradients into +-lr updates.
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer).double()
+    tr = Trainer(model)
+    tr.step({k: v.double() for k, v in _batch(4, 8, 8, 7).items()})
+    for n, p_ in model.named_parameters():
+        g = a["grads"][n]
+        err = float((p_.grad - g).abs().max()) / float(g.abs().max() + 1e-300)
+        assert err <= 1e-9, (n, err)
+
+
+@pytest.mark.gpu
+def test_training_through_the_kernels_reduces_the_loss():
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer, make_training_batch
+    dev = "cuda"
+    batch, volradius = make_training_batch(4, 64, 64, 256, dev, seed=3, target_decoder=SlabDecoderStandIn(256, seed=9))
+    model = RaymarchTrainModel(SlabDecoderStandIn(256, seed=1), volradius).to(dev)
+    tr = Trainer(model, lr=2e-2)          # larger step than the reference's 2e-4 so that 40 iterations show progress
+    first = None
+    for it in range(40):
+        loss, parts = tr.step(batch)
+        if first is None:
+            first = float(loss)
+    last = float(loss)
+    assert np.isfinite(last) and last < 0.8 * first, (first, last)
+    for p in tr.params:
+        assert torch.isfinite(p).all()
