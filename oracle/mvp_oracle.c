@@ -254,12 +254,24 @@ static inline real fade_of(const real *y, real fadescale, real fadeexp) { /* pri
  * mvpraymarch.py:147-152).  stats (may be NULL): [0] rays with >=1 hit, [1] sum of list lengths,
  * [2] evaluated samples, [3] list overflows, [4] march steps, [5] saturated rays.
  * ------------------------------------------------------------------------------------------ */
+/* trilinear lookup of a C-channel channels-last grid at box coordinate y (utils.h:408-502); zero padding */
+static void tri_fetch(const real *G, int C, const tri_t *tr, real *out) {
+    for (int ch = 0; ch < C; ++ch) out[ch] = 0;
+    for (int c = 0; c < 8; ++c)
+        if (tr->idx[c] >= 0)
+            for (int ch = 0; ch < C; ++ch) out[ch] += G[(size_t)tr->idx[c] * C + ch] * tr->w[c];
+}
+
+/* warp may be NULL (algo 0).  With a warp field [N,K,WD,WH,WW,3] the template is sampled at y1 = warp(y0)
+ * (PrimSamplerTW<true>, primsampler.h:53-58); the fade still uses y0. */
 int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const real *raydir, real stepsize,
                        const real *tminmax, const real *nodeaabb, const real *primpos, const real *primrot,
-                       const real *primscale, int TD, int TH, int TW, const real *tplate, real *rayrgba,
-                       real *raysat, real fadescale, real fadeexp, int maxhitboxes, long long *stats) {
+                       const real *primscale, int TD, int TH, int TW, const real *tplate, int WD, int WH, int WW,
+                       const real *warp, real *rayrgba, real *raysat, real fadescale, real fadeexp, int maxhitboxes,
+                       long long *stats) {
     const int nn = 2 * K - 1;
     const size_t V = (size_t)TD * TH * TW;
+    const size_t VW = (size_t)WD * WH * WW;
     long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;
     if (maxhitboxes <= 0) maxhitboxes = 512;
 #pragma omp parallel reduction(+ : st0, st1, st2, st3, st4, st5)
@@ -299,13 +311,17 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
                         if (srt_valid(s.y) && !sat && t < rtmax + (real)1e-5) {
                             st2 += 1;
                             real fade = fade_of(s.y, fadescale, fadeexp);
+                            real y1[3] = {s.y[0], s.y[1], s.y[2]};
+                            if (warp) {
+                                tri_t tw;
+                                tri_setup(WD, WH, WW, s.y, &tw);
+                                tri_fetch(warp + ((size_t)n * K + k) * VW * 3, 3, &tw, y1);
+                            }
                             tri_t tr;
-                            tri_setup(TD, TH, TW, s.y, &tr);
-                            real v[4] = {0, 0, 0, 0};
+                            tri_setup(TD, TH, TW, y1, &tr);
+                            real v[4];
                             const real *Tk = T + (size_t)k * V * 4;
-                            for (int c = 0; c < 8; ++c)
-                                if (tr.idx[c] >= 0)
-                                    for (int ch = 0; ch < 4; ++ch) v[ch] += Tk[(size_t)tr.idx[c] * 4 + ch] * tr.w[c];
+                            tri_fetch(Tk, 4, &tr, v);
                             v[3] *= fade;
                             /* primaccum.h:63-79 */
                             real newalpha = rgba[3] + v[3] * stepsize;
@@ -359,11 +375,13 @@ static inline void atomic_add(real *p, real v) {
  * ------------------------------------------------------------------------------------------ */
 int mvpo_march_backward(int N, int H, int W, int K, const real *raypos, const real *raydir, real stepsize,
                         const real *tminmax, const real *nodeaabb, const real *primpos, const real *primrot,
-                        const real *primscale, int TD, int TH, int TW, const real *tplate, const real *raysat,
-                        const real *grad_rayrgba, real *grad_primpos, real *grad_primrot, real *grad_primscale,
-                        real *grad_tplate, real fadescale, real fadeexp, int maxhitboxes) {
+                        const real *primscale, int TD, int TH, int TW, const real *tplate, int WD, int WH, int WW,
+                        const real *warp, const real *raysat, const real *grad_rayrgba, real *grad_primpos,
+                        real *grad_primrot, real *grad_primscale, real *grad_tplate, real *grad_warp, real fadescale,
+                        real fadeexp, int maxhitboxes) {
     const int nn = 2 * K - 1;
     const size_t V = (size_t)TD * TH * TW;
+    const size_t VW = (size_t)WD * WH * WW;
     if (maxhitboxes <= 0) maxhitboxes = 512;
 #pragma omp parallel
     {
@@ -402,14 +420,20 @@ int mvpo_march_backward(int N, int H, int W, int K, const real *raypos, const re
                     srt_forward(pp + (size_t)k * 3, R, sc, x, &s);
                     if (!(srt_valid(s.y) && !sat && t < rtmax + (real)1e-5)) continue;
                     real fade = fade_of(s.y, fadescale, fadeexp);
+                    real y1[3] = {s.y[0], s.y[1], s.y[2]};
+                    tri_t tw;
+                    const real *Wk = NULL;
+                    if (warp) {
+                        Wk = warp + ((size_t)n * K + k) * VW * 3;
+                        tri_setup(WD, WH, WW, s.y, &tw);
+                        tri_fetch(Wk, 3, &tw, y1);
+                    }
                     tri_t tr;
-                    tri_setup(TD, TH, TW, s.y, &tr);
+                    tri_setup(TD, TH, TW, y1, &tr);
                     const real *Tk = T + (size_t)k * V * 4;
                     real *gTk = gT + (size_t)k * V * 4;
-                    real v[4] = {0, 0, 0, 0};
-                    for (int c = 0; c < 8; ++c)
-                        if (tr.idx[c] >= 0)
-                            for (int ch = 0; ch < 4; ++ch) v[ch] += Tk[(size_t)tr.idx[c] * 4 + ch] * tr.w[c];
+                    real v[4];
+                    tri_fetch(Tk, 4, &tr, v);
                     v[3] *= fade; /* sample.w (primsampler.h:63) */
                     /* primaccum.h:81-98 */
                     real a = v[3] * stepsize;
@@ -440,26 +464,55 @@ int mvpo_march_backward(int N, int H, int W, int K, const real *raypos, const re
                         gy[j] = dfade * v[3] * dLs[3];
                     }
                     dLs[3] *= fade;
-                    /* utils.h:582-642: scatter to the 8 corners, then position gradient */
-                    real gi[3] = {0, 0, 0};
-                    for (int c = 0; c < 8; ++c) {
-                        if (tr.idx[c] < 0) continue;
-                        real dot = 0;
-                        for (int ch = 0; ch < 4; ++ch) {
-                            atomic_add(gTk + (size_t)tr.idx[c] * 4 + ch, tr.w[c] * dLs[ch]);
-                            dot += Tk[(size_t)tr.idx[c] * 4 + ch] * dLs[ch];
+                    /* utils.h:582-642 on the template at y1: scatter to the 8 corners, then d/d(y1) */
+                    real g1[3];
+                    {
+                        real gi[3] = {0, 0, 0};
+                        for (int c = 0; c < 8; ++c) {
+                            if (tr.idx[c] < 0) continue;
+                            real dot = 0;
+                            for (int ch = 0; ch < 4; ++ch) {
+                                atomic_add(gTk + (size_t)tr.idx[c] * 4 + ch, tr.w[c] * dLs[ch]);
+                                dot += Tk[(size_t)tr.idx[c] * 4 + ch] * dLs[ch];
+                            }
+                            int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
+                            real wx = cx ? (tr.f[0] - (real)tr.i0[0]) : ((real)(tr.i0[0] + 1) - tr.f[0]);
+                            real wy = cy ? (tr.f[1] - (real)tr.i0[1]) : ((real)(tr.i0[1] + 1) - tr.f[1]);
+                            real wz = cz ? (tr.f[2] - (real)tr.i0[2]) : ((real)(tr.i0[2] + 1) - tr.f[2]);
+                            gi[0] += (cx ? (real)1 : (real)-1) * wy * wz * dot;
+                            gi[1] += (cy ? (real)1 : (real)-1) * wx * wz * dot;
+                            gi[2] += (cz ? (real)1 : (real)-1) * wx * wy * dot;
                         }
-                        int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
-                        real wx = cx ? (tr.f[0] - (real)tr.i0[0]) : ((real)(tr.i0[0] + 1) - tr.f[0]);
-                        real wy = cy ? (tr.f[1] - (real)tr.i0[1]) : ((real)(tr.i0[1] + 1) - tr.f[1]);
-                        real wz = cz ? (tr.f[2] - (real)tr.i0[2]) : ((real)(tr.i0[2] + 1) - tr.f[2]);
-                        gi[0] += (cx ? (real)1 : (real)-1) * wy * wz * dot;
-                        gi[1] += (cy ? (real)1 : (real)-1) * wx * wz * dot;
-                        gi[2] += (cz ? (real)1 : (real)-1) * wx * wy * dot;
+                        g1[0] = (real)(TW - 1) / (real)2 * gi[0];
+                        g1[1] = (real)(TH - 1) / (real)2 * gi[1];
+                        g1[2] = (real)(TD - 1) / (real)2 * gi[2];
                     }
-                    gy[0] += (real)(TW - 1) / (real)2 * gi[0];
-                    gy[1] += (real)(TH - 1) / (real)2 * gi[1];
-                    gy[2] += (real)(TD - 1) / (real)2 * gi[2];
+                    if (warp) { /* primsampler.h:82-85: scatter dL_y1 into the warp field, chain to y0 */
+                        real *gWk = grad_warp + ((size_t)n * K + k) * VW * 3;
+                        real gi[3] = {0, 0, 0};
+                        for (int c = 0; c < 8; ++c) {
+                            if (tw.idx[c] < 0) continue;
+                            real dot = 0;
+                            for (int ch = 0; ch < 3; ++ch) {
+                                atomic_add(gWk + (size_t)tw.idx[c] * 3 + ch, tw.w[c] * g1[ch]);
+                                dot += Wk[(size_t)tw.idx[c] * 3 + ch] * g1[ch];
+                            }
+                            int cx = c & 1, cy = (c >> 1) & 1, cz = (c >> 2) & 1;
+                            real wx = cx ? (tw.f[0] - (real)tw.i0[0]) : ((real)(tw.i0[0] + 1) - tw.f[0]);
+                            real wy = cy ? (tw.f[1] - (real)tw.i0[1]) : ((real)(tw.i0[1] + 1) - tw.f[1]);
+                            real wz = cz ? (tw.f[2] - (real)tw.i0[2]) : ((real)(tw.i0[2] + 1) - tw.f[2]);
+                            gi[0] += (cx ? (real)1 : (real)-1) * wy * wz * dot;
+                            gi[1] += (cy ? (real)1 : (real)-1) * wx * wz * dot;
+                            gi[2] += (cz ? (real)1 : (real)-1) * wx * wy * dot;
+                        }
+                        gy[0] += (real)(WW - 1) / (real)2 * gi[0];
+                        gy[1] += (real)(WH - 1) / (real)2 * gi[1];
+                        gy[2] += (real)(WD - 1) / (real)2 * gi[2];
+                    } else {
+                        gy[0] += g1[0];
+                        gy[1] += g1[1];
+                        gy[2] += g1[2];
+                    }
                     /* primtransf.h:155-179 */
                     real g2[3];
                     for (int j = 0; j < 3; ++j) {

@@ -71,7 +71,7 @@ class Oracle:
         return out
 
     def march_forward(self, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template,
-                      fadescale=8.0, fadeexp=8.0, maxhitboxes=512, want_raysat=True, nodeaabb=None):
+                      fadescale=8.0, fadeexp=8.0, maxhitboxes=512, want_raysat=True, nodeaabb=None, warp=None):
         raypos, raydir, tminmax, primpos, primrot, primscale, template = map(
             self._a, (raypos, raydir, tminmax, primpos, primrot, primscale, template))
         N, H, W = raypos.shape[:3]
@@ -84,17 +84,24 @@ class Oracle:
         rgba = np.empty((N, H, W, 4), self.dtype)
         raysat = np.empty((N, H, W, 3), self.dtype) if want_raysat else None
         stats = np.zeros(8, np.int64)
+        WD = WH = WW = 0
+        if warp is not None:
+            warp = self._a(warp)
+            WD, WH, WW = warp.shape[2:5]
+            assert warp.shape[5] == 3
         rc = self.lib.mvpo_march_forward(
             N, H, W, K, self._p(raypos), self._p(raydir), self._creal(stepsize), self._p(tminmax),
             self._p(nodeaabb), self._p(primpos), self._p(primrot), self._p(primscale), TD, TH, TW,
-            self._p(template), self._p(rgba), self._p(raysat), self._creal(fadescale), self._creal(fadeexp),
-            int(maxhitboxes), stats.ctypes.data_as(ctypes.c_void_p))
+            self._p(template), WD, WH, WW, self._p(warp), self._p(rgba), self._p(raysat), self._creal(fadescale),
+            self._creal(fadeexp), int(maxhitboxes), stats.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0
         names = ["rays_hit", "list_len_sum", "samples", "list_overflow", "steps", "rays_saturated"]
         return rgba, raysat, dict(zip(names, stats[:6].tolist()))
 
     def march_backward(self, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, raysat,
-                       grad_rayrgba, fadescale=8.0, fadeexp=8.0, maxhitboxes=512, nodeaabb=None):
+                       grad_rayrgba, fadescale=8.0, fadeexp=8.0, maxhitboxes=512, nodeaabb=None, warp=None):
+        """Returns (grad_primpos, grad_primrot, grad_primscale, grad_template) and, with a warp field, grad_warp as a
+        fifth element."""
         (raypos, raydir, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba) = map(
             self._a, (raypos, raydir, tminmax, primpos, primrot, primscale, template, raysat, grad_rayrgba))
         N, H, W = raypos.shape[:3]
@@ -107,10 +114,19 @@ class Oracle:
         grot = np.zeros_like(primrot)
         gscale = np.zeros_like(primscale)
         gtpl = np.zeros_like(template)
+        WD = WH = WW = 0
+        gwarp = None
+        if warp is not None:
+            warp = self._a(warp)
+            WD, WH, WW = warp.shape[2:5]
+            gwarp = np.zeros_like(warp)
         rc = self.lib.mvpo_march_backward(
             N, H, W, K, self._p(raypos), self._p(raydir), self._creal(stepsize), self._p(tminmax),
             self._p(nodeaabb), self._p(primpos), self._p(primrot), self._p(primscale), TD, TH, TW,
-            self._p(template), self._p(raysat), self._p(grad_rayrgba), self._p(gpos), self._p(grot),
-            self._p(gscale), self._p(gtpl), self._creal(fadescale), self._creal(fadeexp), int(maxhitboxes))
+            self._p(template), WD, WH, WW, self._p(warp), self._p(raysat), self._p(grad_rayrgba), self._p(gpos),
+            self._p(grot), self._p(gscale), self._p(gtpl), self._p(gwarp), self._creal(fadescale),
+            self._creal(fadeexp), int(maxhitboxes))
         assert rc == 0
+        if warp is not None:
+            return gpos, grot, gscale, gtpl, gwarp
         return gpos, grot, gscale, gtpl

@@ -33,7 +33,7 @@ class _Captured(Exception):
     pass
 
 
-def run_reference_gradcheck(N, H, W, k3, M, fadescale, fadeexp, alpha_shift=None):
+def run_reference_gradcheck(N, H, W, k3, M, fadescale, fadeexp, alpha_shift=None, dowarp=False):
     torch.set_default_dtype(torch.float64)
     sys.modules["mvpraymarchlib"] = types.ModuleType("mvpraymarchlib")  # CUDA module stand-in
     src = open(os.path.join(REF, "extensions/mvpraymarch/mvpraymarch.py")).read()
@@ -60,7 +60,7 @@ def run_reference_gradcheck(N, H, W, k3, M, fadescale, fadeexp, alpha_shift=None
         f = sys._getframe(1).f_locals
         cap["args"] = dict(raypos=raypos, raydir=raydir, stepsize=stepsize, tminmax=tminmax,
                            primpos=primtransf[0], primrot=primtransf[1], primscale=primtransf[2],
-                           template=template, kw=kw)
+                           template=template, warp=warp, kw=kw)
         cap["sample0"] = f["sample0"]
         cap["grads0"] = dict(zip(f["paramnames"], f["grads0"]))
         cap["raw"] = dict(_template=f["_template"], _primscale=f["_primscale"])
@@ -69,8 +69,9 @@ def run_reference_gradcheck(N, H, W, k3, M, fadescale, fadeexp, alpha_shift=None
     ns["mvpraymarch"] = capture
     t0 = time.time()
     try:
-        ns["gradcheck"](usebvh="fixedorder", sortprims=False, maxhitboxes=512, synchitboxes=True, dowarp=False,
-                        chlast=True, fadescale=fadescale, fadeexp=fadeexp, accum=0, algo=0, griddim=3)
+        ns["gradcheck"](usebvh="fixedorder", sortprims=False, maxhitboxes=512, synchitboxes=True, dowarp=dowarp,
+                        chlast=True, fadescale=fadescale, fadeexp=fadeexp, accum=0, algo=1 if dowarp else 0,
+                        griddim=3)
     except _Captured:
         pass
     cap["seconds"] = time.time() - t0
@@ -96,6 +97,9 @@ def save_march(name, **cfg):
         graw_primscale=cap["grads0"]["primscale"],
         chain_template=chain_template, chain_primpos=np.float64(0.3), chain_primscale=0.1 * a["primscale"],
     )
+    if a["warp"] is not None:  # the second instantiation the reference ships: warp-field sampler, algo 1
+        out["warp"] = a["warp"]                                                             # [N,K,WD,WH,WW,3]
+        out["graw_warp"] = cap["grads0"]["warp"].permute(0, 1, 3, 4, 5, 2).contiguous()     # raw leaf == warp
     out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
     for k, v in out.items():
         assert v.dtype in (np.float64,), (k, v.dtype)
@@ -152,4 +156,8 @@ if __name__ == "__main__":
     save_march("march_k64_m4", N=2, H=13, W=13, k3=4, M=4, fadescale=8.0, fadeexp=8.0)
     # dense opacity: most rays saturate -> exercises the raysat backward rule (primaccum.h:86-93)
     save_march("march_k8_m8_sat", N=1, H=15, W=15, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0)
+    # warp-field sampler (mvpraymarch.py:762-774: dowarp=True, algo=1), warp grid M/2
+    save_march("march_warp_k8_m8", N=2, H=15, W=15, k3=2, M=8, fadescale=6.5, fadeexp=7.5, dowarp=True)
+    save_march("march_warp_k8_m8_sat", N=1, H=13, W=13, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0,
+               dowarp=True)
     save_raydirs("raydirs_small")

@@ -12,17 +12,21 @@ import pytest
 
 from conftest import GOLDEN
 
-MARCH = ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat"]
+MARCH = ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat", "march_warp_k8_m8", "march_warp_k8_m8_sat"]
 
 
 def _run(o, g):
     args = (g["raypos"], g["raydir"], float(g["stepsize"]), g["tminmax"], g["primpos"], g["primrot"],
             g["primscale"], g["template"])
     fs, fe = float(g["fadescale"]), float(g["fadeexp"])
-    rgba, raysat, st = o.march_forward(*args, fs, fe)
-    gp, gr, gs, gt = o.march_backward(*args, raysat, np.ones_like(rgba), fs, fe)
+    warp = g["warp"] if "warp" in g.files else None   # warp-field sampler goldens (algo 1, mvpraymarch.py:762-774)
+    rgba, raysat, st = o.march_forward(*args, fs, fe, warp=warp)
+    grads = o.march_backward(*args, raysat, np.ones_like(rgba), fs, fe, warp=warp)
+    gp, gr, gs, gt = grads[:4]
     mine = dict(template=gt * g["chain_template"], primpos=gp * g["chain_primpos"], primrot=gr,
                 primscale=gs * g["chain_primscale"])
+    if warp is not None:
+        mine["warp"] = grads[4]
     return rgba, raysat, st, mine
 
 
@@ -48,7 +52,7 @@ def test_oracle_f32_within_fp32_tolerance(oracle32, name):
     assert np.abs(rgba - g["rgba"]).max() <= 2e-4 * max(1.0, np.abs(g["rgba"]).max())
     ref = g["graw_template"]
     assert np.abs(mine["template"] - ref).max() <= 1e-3 * np.abs(ref).max()
-    for k in ("primpos", "primrot", "primscale"):
+    for k in ("primpos", "primrot", "primscale") + (("warp",) if "warp" in mine else ()):
         ref = g["graw_" + k]
         cos = (mine[k] * ref).sum() / np.sqrt((mine[k] ** 2).sum() * (ref ** 2).sum())
         assert cos >= 0.9999, (k, cos)
