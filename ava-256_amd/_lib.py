@@ -19,15 +19,17 @@ SIGNATURES = {
     "mvp_raydirs_forward": (_c_int, [_c_int] * 3 + [_c_void_p] * 5 + [_c_float] + [_c_void_p] * 3 + [_c_void_p]),
     "mvp_aabb_build": (_c_int, [_c_int] * 2 + [_c_void_p] * 4 + [_c_void_p]),
     # N,H,W,K | raypos,raydir | stepsize | tminmax,nodeaabb,primpos,primrot,primscale | TD,TH,TW |
-    # tplate,rayrgba,raysat,rayaux,primlist_count,primlist | primlist_cap | fadescale,fadeexp | diag,stream
+    # tplate | WD,WH,WW | warp,rayrgba,raysat,rayaux,primlist_count,primlist | primlist_cap | fadescale,fadeexp |
+    # diag,stream
     "mvp_march_forward": (_c_int, [_c_int] * 4 + [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 5 + [_c_int] * 3 +
-                          [_c_void_p] * 6 + [_c_int] + [_c_float] * 2 + [_c_void_p] * 2),
-    # ... | tplate,raysat,rayaux,primlist_count,primlist | primlist_cap | grad_rayrgba,g_pos,g_rot,g_scale,g_tplate |
-    # fadescale,fadeexp | diag,stream
+                          [_c_void_p] + [_c_int] * 3 + [_c_void_p] * 6 + [_c_int] + [_c_float] * 2 + [_c_void_p] * 2),
+    # ... | tplate | WD,WH,WW | warp,raysat,rayaux,primlist_count,primlist | primlist_cap |
+    # grad_rayrgba,g_pos,g_rot,g_scale,g_tplate,g_warp | fadescale,fadeexp | diag,stream
     "mvp_march_backward": (_c_int, [_c_int] * 4 + [_c_void_p] * 2 + [_c_float] + [_c_void_p] * 5 + [_c_int] * 3 +
-                           [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 5 + [_c_float] * 2 + [_c_void_p] * 2),
+                           [_c_void_p] + [_c_int] * 3 + [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 6 + [_c_float] * 2 +
+                           [_c_void_p] * 2),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

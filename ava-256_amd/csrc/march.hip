@@ -52,6 +52,9 @@ struct MarchParams {
     int tiles_x, tiles_y, chunk;  // 8x8 packets per image row / column; packets per (image, XCD) chunk
     float stepsize, fadescale, fadeexp;
     const float *raypos, *raydir, *tminmax, *nodeaabb, *primpos, *primrot, *primscale, *tplate;
+    int WD, WH, WW;                              // warp-field grid (algo 1), 0 when absent
+    const float *warp;                           // [N,K,WD,WH,WW,3] or null
+    float *grad_warp;                            // backward, algo 1
     float *rayrgba, *raysat;                     // forward outputs
     const float *raysat_in, *grad_rayrgba;       // backward inputs
     float *grad_primpos, *grad_primrot, *grad_primscale, *grad_tplate;
@@ -197,6 +200,78 @@ __device__ __forceinline__ float4 sample_slab(const float *__restrict__ Tk, f3 y
     return v;
 }
 
+// ---- warp-field path (algo 1: PrimSamplerTW<true>, primsampler.h:53-58,82-88) -------------------------------------
+// The warped coordinate y1 may leave (-1,1)^3, so the template lookup needs the reference's general form: normalised
+// coordinate clamped to +-100, floor, zero padding through per-corner bounds tests (utils.h:414-498).
+struct TriG {
+    int x0, y0, z0;
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+__device__ __forceinline__ TriG tri_general(f3 y, int D, int H, int W) {
+    const float ix = fmaxf(-100.f, fminf(100.f, (y.x + 1.f) * 0.5f)) * (float)(W - 1);
+    const float iy = fmaxf(-100.f, fminf(100.f, (y.y + 1.f) * 0.5f)) * (float)(H - 1);
+    const float iz = fmaxf(-100.f, fminf(100.f, (y.z + 1.f) * 0.5f)) * (float)(D - 1);
+    TriG t;
+    t.x0 = (int)floorf(ix), t.y0 = (int)floorf(iy), t.z0 = (int)floorf(iz);
+    t.wx1 = ix - (float)t.x0, t.wx0 = (float)(t.x0 + 1) - ix;
+    t.wy1 = iy - (float)t.y0, t.wy0 = (float)(t.y0 + 1) - iy;
+    t.wz1 = iz - (float)t.z0, t.wz0 = (float)(t.z0 + 1) - iz;
+    return t;
+}
+__device__ __forceinline__ bool tri_inb(const TriG &t, int c, int D, int H, int W, int &vox, float &w) {
+    const int x = t.x0 + (c & 1), y = t.y0 + ((c >> 1) & 1), z = t.z0 + (c >> 2);
+    w = ((c & 1) ? t.wx1 : t.wx0) * (((c >> 1) & 1) ? t.wy1 : t.wy0) * ((c >> 2) ? t.wz1 : t.wz0);
+    vox = (z * H + y) * W + x;
+    return x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D;
+}
+// y1 = trilinear 3-channel lookup of the warp grid at y0 (y0 strictly inside: every corner is in bounds after the
+// base-corner clamp, same value as the zero-padded form)
+__device__ __forceinline__ f3 warp_lookup(const float *__restrict__ Wk, f3 y0, int D, int H, int W) {
+    TriG t = tri_general(y0, D, H, W);
+    f3 r = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int vox;
+        float w;
+        if (tri_inb(t, c, D, H, W, vox, w)) {
+            const float *q = Wk + (size_t)vox * 3;
+            r.x += q[0] * w, r.y += q[1] * w, r.z += q[2] * w;
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ float4 tplate_lookup_general(const float *__restrict__ Tk, f3 y1, int D, int H, int W) {
+    TriG t = tri_general(y1, D, H, W);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int vox;
+        float w;
+        if (tri_inb(t, c, D, H, W, vox, w)) {
+            const float4 q = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
+            v.x += q.x * w, v.y += q.y * w, v.z += q.z * w, v.w += q.w * w;
+        }
+    }
+    return v;
+}
+template <bool FADE8>
+__device__ __forceinline__ float fade_of(f3 y, float fadescale, float fadeexp) {
+    if (FADE8) {
+        const f3 y2 = y * y, y4 = y2 * y2;
+        return fast_exp(-fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+    }
+    return fast_exp(-fadescale *
+                    (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp) + fast_pow(fabsf(y.z), fadeexp)));
+}
+// d(trilinear)/d(position) in index units for channel-dotted corner values `dotc` (utils.h:592-642): returns
+// (sum +-wy*wz*dot, sum +-wx*wz*dot, sum +-wx*wy*dot) over the in-bounds corners
+__device__ __forceinline__ void tri_posgrad_acc(const TriG &t, int c, float dot, f3 &g) {
+    const float wx = (c & 1) ? t.wx1 : t.wx0, wy = ((c >> 1) & 1) ? t.wy1 : t.wy0, wz = (c >> 2) ? t.wz1 : t.wz0;
+    g.x += ((c & 1) ? 1.f : -1.f) * wy * wz * dot;
+    g.y += (((c >> 1) & 1) ? 1.f : -1.f) * wx * wz * dot;
+    g.z += ((c >> 2) ? 1.f : -1.f) * wx * wy * dot;
+}
+
 // Lattice steps s (t_s = tmin + s*dt) of one ray that can fall strictly inside a box whose slab interval is
 // [tn, tf] (utils.h:747-753), clipped to the ray's [tmin, tmax + 1e-5).  The strict inside test on the evaluated
 // position decides membership exactly as in the reference; this range only has to contain every step that test
@@ -213,7 +288,7 @@ __device__ __forceinline__ bool lane_step_range(float tn, float tf, float tmin, 
     return lo <= hi;
 }
 
-template <bool BWD, bool FADE8>
+template <bool BWD, bool FADE8, bool WARP>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
                                              const bool emit_all) {
     const int lane = lane_id();
@@ -572,8 +647,15 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             const int k = ent & 0xffffff, slot = (ent >> 24) & 0xff;
                             const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
                             const f3 y = rot_rows(q, x - q.pos) * q.scale;
-                            const float4 v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale,
-                                                                p.fadeexp);
+                            float4 v;
+                            if (WARP) {  // primsampler.h:48-63 with dowarp: fade from y0, template sampled at warp(y0)
+                                const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
+                                const f3 y1 = warp_lookup(p.warp + ((size_t)n * K + k) * VW3, y, p.WD, p.WH, p.WW);
+                                v = tplate_lookup_general(T + (size_t)k * V4, y1, p.TD, p.TH, p.TW);
+                                v.w *= fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                            } else {
+                                v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale, p.fadeexp);
+                            }
                             // ---- primaccum.h:63-79 ----
                             const float newalpha = rgba.w + v.w * dt;
                             const float contrib = fminf(newalpha, 1.f) - rgba.w;
@@ -608,7 +690,103 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                     const bool emit = !BWD || emit_all || (p.pl_count[(size_t)n * K + k] > (uint32_t)p.pl_cap);
 
                     f3 gy = mk3(0.f, 0.f, 0.f);  // BWD: dL/dy of this lane's sample (0 when not inside)
-                    if (inside) {
+                    if (BWD && WARP && inside) {
+                        // ---- warp-field sampler, backward (primsampler.h:68-91 with dowarp; utils.h:504-643 twice) ----
+                        const float fade = fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                        f3 ypow;
+                        if (FADE8) {
+                            const f3 y2 = y * y, y4 = y2 * y2;
+                            ypow = y4 * y2 * y;
+                        } else {
+                            const float e1 = p.fadeexp - 1.f;
+                            ypow = mk3(fast_pow(fabsf(y.x), e1) * (y.x > 0.f ? 1.f : -1.f),
+                                       fast_pow(fabsf(y.y), e1) * (y.y > 0.f ? 1.f : -1.f),
+                                       fast_pow(fabsf(y.z), e1) * (y.z > 0.f ? 1.f : -1.f));
+                        }
+                        const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
+                        const float *Wk = p.warp + ((size_t)n * K + k) * VW3;
+                        const TriG tw = tri_general(y, p.WD, p.WH, p.WW);
+                        f3 y1 = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            int vox;
+                            float w;
+                            if (tri_inb(tw, c, p.WD, p.WH, p.WW, vox, w)) {
+                                const float *qw = Wk + (size_t)vox * 3;
+                                y1.x += qw[0] * w, y1.y += qw[1] * w, y1.z += qw[2] * w;
+                            }
+                        }
+                        const float *Tk = T + (size_t)k * V4;
+                        const TriG tt = tri_general(y1, p.TD, p.TH, p.TW);
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            int vox;
+                            float w;
+                            if (tri_inb(tt, c, p.TD, p.TH, p.TW, vox, w)) {
+                                const float4 qv = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
+                                v.x += qv.x * w, v.y += qv.y * w, v.z += qv.z * w, v.w += qv.w * w;
+                            }
+                        }
+                        const float alpha = v.w * fade;
+                        // ---- primaccum.h:81-98 ----
+                        const float a = alpha * dt;
+                        const bool thissat = rgba.w + a >= 1.f;
+                        sat = sat || thissat;
+                        const float weight = sat ? (1.f - rgba.w) : a;
+                        float4 dLs;
+                        dLs.x = weight * dL3.x;
+                        dLs.y = weight * dL3.y;
+                        dLs.z = weight * dL3.z;
+                        dLs.w = sat ? 0.f
+                                    : dt * ((v.x - (has_sat ? rsat_in.x : 0.f)) * dL3.x +
+                                            (v.y - (has_sat ? rsat_in.y : 0.f)) * dL3.y +
+                                            (v.z - (has_sat ? rsat_in.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
+                        rgba.x += v.x * weight;
+                        rgba.y += v.y * weight;
+                        rgba.z += v.z * weight;
+                        rgba.w += weight;
+                        if (emit) {
+                            const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                            gy = ypow * gf;
+                            dLs.w *= fade;
+                            float *gTk = gT + (size_t)k * V4;
+                            f3 gi1 = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                int vox;
+                                float w;
+                                if (tri_inb(tt, c, p.TD, p.TH, p.TW, vox, w)) {
+                                    const float4 qv = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
+                                    float *g = gTk + (size_t)vox * 4;
+                                    atomicAdd(g + 0, w * dLs.x);
+                                    atomicAdd(g + 1, w * dLs.y);
+                                    atomicAdd(g + 2, w * dLs.z);
+                                    atomicAdd(g + 3, w * dLs.w);
+                                    tri_posgrad_acc(tt, c, qv.x * dLs.x + qv.y * dLs.y + qv.z * dLs.z + qv.w * dLs.w, gi1);
+                                }
+                            }
+                            const f3 g1 = mk3(mx * gi1.x, my * gi1.y, mz * gi1.z);  // dL/dy1
+                            float *gWk = p.grad_warp + ((size_t)n * K + k) * VW3;
+                            f3 gi0 = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                int vox;
+                                float w;
+                                if (tri_inb(tw, c, p.WD, p.WH, p.WW, vox, w)) {
+                                    const float *qw = Wk + (size_t)vox * 3;
+                                    float *g = gWk + (size_t)vox * 3;
+                                    atomicAdd(g + 0, w * g1.x);
+                                    atomicAdd(g + 1, w * g1.y);
+                                    atomicAdd(g + 2, w * g1.z);
+                                    tri_posgrad_acc(tw, c, qw[0] * g1.x + qw[1] * g1.y + qw[2] * g1.z, gi0);
+                                }
+                            }
+                            gy.x += 0.5f * (float)(p.WW - 1) * gi0.x;
+                            gy.y += 0.5f * (float)(p.WH - 1) * gi0.y;
+                            gy.z += 0.5f * (float)(p.WD - 1) * gi0.z;
+                        }
+                    } else if (inside) {
                         // ---- fade (primsampler.h:48-51) ----
                         float fade;
                         f3 ypow;  // |y|^(fadeexp-1) * sgn(y), backward only
@@ -796,7 +974,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
 }
 
-template <bool BWD, bool FADE8>
+template <bool BWD, bool FADE8, bool WARP>
 __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     __shared__ int s_a[kMaxList];
     __shared__ int s_b[kMaxList];
@@ -809,11 +987,11 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
             emit_all = (flags & kFlagGlobal) != 0u;
         }
         for (int b = blockIdx.x; b < p.total_packets; b += gridDim.x) {
-            march_packet<BWD, FADE8>(p, b, s_a, s_b, s_rec, emit_all);
+            march_packet<BWD, FADE8, WARP>(p, b, s_a, s_b, s_rec, emit_all);
             __syncthreads();
         }
     } else {
-        march_packet<BWD, FADE8>(p, blockIdx.x, s_a, s_b, s_rec, true);
+        march_packet<BWD, FADE8, WARP>(p, blockIdx.x, s_a, s_b, s_rec, true);
     }
 }
 
@@ -1309,12 +1487,15 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
 extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir,
                                  float stepsize, const float *tminmax, const float *nodeaabb, const float *primpos,
                                  const float *primrot, const float *primscale, int TD, int TH, int TW,
-                                 const float *tplate, float *rayrgba, float *raysat, uint32_t *rayaux,
-                                 uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale,
-                                 float fadeexp, uint32_t *diag, void *stream) {
+                                 const float *tplate, int WD, int WH, int WW, const float *warp, float *rayrgba,
+                                 float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
+                                 int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream) {
     using namespace mvp;
     MarchParams p = {};
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
+    p.WD = WD, p.WH = WH, p.WW = WW, p.warp = warp;
+    if (warp && (WD < 2 || WH < 2 || WW < 2)) return MVP_ERR_UNSUPPORTED;
+    if (warp) rayaux = nullptr, primlist_count = nullptr, primlist = nullptr;  // algo 1: ray-centric backward only
     p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
     p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
     p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
@@ -1345,24 +1526,35 @@ extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos
     }
     const bool fade8 = fadeexp == 8.0f;
     const dim3 grid((unsigned)p.total_packets), block(kWave);
-    if (fade8)
-        hipLaunchKernelGGL((march_kernel<false, true>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((march_kernel<false, false>), grid, block, 0, st, p);
+    if (warp) {
+        if (fade8)
+            hipLaunchKernelGGL((march_kernel<false, true, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_kernel<false, false, true>), grid, block, 0, st, p);
+    } else {
+        if (fade8)
+            hipLaunchKernelGGL((march_kernel<false, true, false>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_kernel<false, false, false>), grid, block, 0, st, p);
+    }
     return launch_status();
 }
 
 extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir,
                                   float stepsize, const float *tminmax, const float *nodeaabb,
                                   const float *primpos, const float *primrot, const float *primscale, int TD,
-                                  int TH, int TW, const float *tplate, const float *raysat, const uint32_t *rayaux,
-                                  uint32_t *primlist_count, const uint32_t *primlist, int primlist_cap,
-                                  const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
-                                  float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp,
+                                  int TH, int TW, const float *tplate, int WD, int WH, int WW, const float *warp,
+                                  const float *raysat, const uint32_t *rayaux, uint32_t *primlist_count,
+                                  const uint32_t *primlist, int primlist_cap, const float *grad_rayrgba,
+                                  float *grad_primpos, float *grad_primrot, float *grad_primscale,
+                                  float *grad_tplate, float *grad_warp, float fadescale, float fadeexp,
                                   uint32_t *diag, void *stream) {
     using namespace mvp;
     MarchParams p = {};
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
+    p.WD = WD, p.WH = WH, p.WW = WW, p.warp = warp, p.grad_warp = grad_warp;
+    if (warp && (WD < 2 || WH < 2 || WW < 2)) return MVP_ERR_UNSUPPORTED;
+    if (warp && !grad_warp) return MVP_ERR_BADARG;
     p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
     p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
     p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
@@ -1385,13 +1577,15 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
     const size_t lds = V * 16 + Vp * 48 + 512 * 16 + 64 * sizeof(float) + 16 + 32 * 4;
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
-    const bool prim_path = !norays && have_lists && lds <= 64 * 1024;
+    const bool prim_path = !norays && have_lists && lds <= 64 * 1024 && warp == nullptr;
     const bool fade8 = fadeexp == 8.0f;
     if (!prim_path) {  // ray-centric backward owns everything: it accumulates, so zero-fill first
         hipError_t e = hipMemsetAsync(grad_tplate, 0, sizeof(float) * 4 * V * (size_t)N * K, st);
         if (e == hipSuccess) e = hipMemsetAsync(grad_primpos, 0, sizeof(float) * 3 * (size_t)N * K, st);
         if (e == hipSuccess) e = hipMemsetAsync(grad_primrot, 0, sizeof(float) * 9 * (size_t)N * K, st);
         if (e == hipSuccess) e = hipMemsetAsync(grad_primscale, 0, sizeof(float) * 3 * (size_t)N * K, st);
+        if (e == hipSuccess && warp)
+            e = hipMemsetAsync(grad_warp, 0, sizeof(float) * 3 * (size_t)WD * WH * WW * (size_t)N * K, st);
         if (e != hipSuccess) return (int)e;
         if (norays) return MVP_OK;
         p.fallback_all = 1;
@@ -1417,9 +1611,16 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     int fb = p.total_packets;
     if (!p.fallback_all && fb > 256 * 16) fb = 256 * 16;  // persistent-style grid for the rarely-taken path
     const dim3 grid((unsigned)fb), block(kWave);
-    if (fade8)
-        hipLaunchKernelGGL((march_kernel<true, true>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((march_kernel<true, false>), grid, block, 0, st, p);
+    if (warp) {
+        if (fade8)
+            hipLaunchKernelGGL((march_kernel<true, true, true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_kernel<true, false, true>), grid, block, 0, st, p);
+    } else {
+        if (fade8)
+            hipLaunchKernelGGL((march_kernel<true, true, false>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_kernel<true, false, false>), grid, block, 0, st, p);
+    }
     return launch_status();
 }

@@ -56,8 +56,12 @@ class MVPRaymarch(Function):
                 gradmode, options):
         algo = options["algo"]
         usebvh = options["usebvh"]
-        if warp is not None or algo != 0:
-            raise NotImplementedError("warp-field sampling (algo 1) is not part of this build yet")
+        if algo not in (0, 1):
+            raise NotImplementedError("algo must be 0 (slab sampler) or 1 (warp-field sampler)")
+        if algo == 1 and warp is None:
+            raise RuntimeError("algo=1 needs a warp field")
+        if algo == 0:
+            warp = None  # PrimSamplerTW<false> never reads it (mvpraymarch_kernel.cu:89-95)
         if usebvh != "fixedorder":
             raise NotImplementedError("only usebvh='fixedorder' is implemented")
         if options.get("randomorder", False):
@@ -83,6 +87,11 @@ class MVPRaymarch(Function):
         assert template.dim() == 6 and template.size(-1) == 4 and template.shape[:2] == (N, K)
         TD, TH, TW = template.size(2), template.size(3), template.size(4)
         dev = raypos.device
+        WD = WH = WW = 0
+        if warp is not None:
+            warp = aligned(require_device_f32("warp", warp))
+            assert warp.dim() == 6 and warp.size(-1) == 3 and warp.shape[:2] == (N, K)   # mvpraymarch.py:124
+            WD, WH, WW = warp.size(2), warp.size(3), warp.size(4)
 
         raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
         _, _, nodeaabb = build_accel((primpos, primrot, primscale), algo, fixedorder=True)
@@ -92,7 +101,7 @@ class MVPRaymarch(Function):
         pl_cap = 0
         if gradmode:
             raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
-            if not _hooks.force_ray_centric_backward:
+            if not _hooks.force_ray_centric_backward and warp is None:
                 # hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record
                 # and, per primitive, the list of ray packets that touch it
                 pl_cap = primlist_capacity(H, W, K)
@@ -102,14 +111,14 @@ class MVPRaymarch(Function):
         with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
             _lib.check(_lib.get_lib().mvp_march_forward(
                 N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
-                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(rayrgba), ptr(raysat), ptr(rayaux),
-                ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag), stream_ptr(dev)),
-                "mvp_march_forward")
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(rayrgba),
+                ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag),
+                stream_ptr(dev)), "mvp_march_forward")
 
         if _hooks.keep_raysat:
             _hooks.last_raysat = raysat
         ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
-                              pl_count, pl_list)
+                              pl_count, pl_list, warp)
         ctx.pl_cap = pl_cap
         ctx.options = options
         ctx.stepsize = float(stepsize)
@@ -118,7 +127,7 @@ class MVPRaymarch(Function):
     @staticmethod
     def backward(ctx, grad_rayrgba):
         (raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux, pl_count,
-         pl_list) = ctx.saved_tensors
+         pl_list, warp) = ctx.saved_tensors
         if raysat is None:
             raise RuntimeError("backward through mvpraymarch needs grad mode enabled during the forward call")
         fadescale, fadeexp = float(ctx.options["fadescale"]), float(ctx.options["fadeexp"])
@@ -134,14 +143,16 @@ class MVPRaymarch(Function):
         grad_primrot = torch.empty_like(primrot)
         grad_primscale = torch.empty_like(primscale)
         grad_template = torch.empty_like(template)
+        grad_warp = torch.empty_like(warp) if warp is not None else None
+        WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
         with torch.cuda.device(dev), _hooks.timed("march_backward", dev):
             _lib.check(_lib.get_lib().mvp_march_backward(
                 N, H, W, K, ptr(raypos), ptr(raydir), ctx.stepsize, ptr(tminmax), ptr(nodeaabb), ptr(primpos),
-                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), ptr(raysat), ptr(rayaux), ptr(pl_count),
-                ptr(pl_list), ctx.pl_cap, ptr(grad_rayrgba), ptr(grad_primpos), ptr(grad_primrot),
-                ptr(grad_primscale), ptr(grad_template), fadescale, fadeexp, ptr(_hooks.diag), stream_ptr(dev)),
-                "mvp_march_backward")
-        return (None, None, None, None, grad_primpos, grad_primrot, grad_primscale, grad_template, None, None,
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(raysat),
+                ptr(rayaux), ptr(pl_count), ptr(pl_list), ctx.pl_cap, ptr(grad_rayrgba), ptr(grad_primpos),
+                ptr(grad_primrot), ptr(grad_primscale), ptr(grad_template), ptr(grad_warp), fadescale, fadeexp,
+                ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_backward")
+        return (None, None, None, None, grad_primpos, grad_primrot, grad_primscale, grad_template, grad_warp, None,
                 None, None)
 
 

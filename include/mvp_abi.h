@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 2
+#define MVP_ABI_VERSION 3
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -76,7 +76,9 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
 
 /* Forward march.  Replaces raymarch_forward_cuda (mvpraymarch.cpp:38-66, mvpraymarch_kernel.cu:35-120,
  * mvpraymarch_subset_kernel.h:7-100) for algo 0 / fixedorder / channels-last / additive accumulation,
- * the only instantiation the training path reaches.  raysat may be NULL (no-grad mode,
+ * the instantiation the training path reaches, and -- when `warp` is given -- for algo 1, the warp-field
+ * sampler PrimSamplerTW<true> (primsampler.h:53-58; mvpraymarch_kernel.cu:83-88,102): warp is [N,K,WD,WH,WW,3]
+ * channels-last, the slab is sampled at warp(y) while the fade uses y.  raysat may be NULL (no-grad mode,
  * mvpraymarch.py:147-152); when given it is fully written (-1 where the ray never saturates).
  *
  * Grad-mode hand-off to the backward (all three may be NULL; then the backward uses its ray-centric path):
@@ -88,23 +90,25 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
 int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                       const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
-                      const float *primscale, int TD, int TH, int TW, const float *tplate, float *rayrgba,
-                      float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
-                      int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream);
+                      const float *primscale, int TD, int TH, int TW, const float *tplate, int WD, int WH, int WW,
+                      const float *warp /*or NULL*/, float *rayrgba, float *raysat, uint32_t *rayaux,
+                      uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale, float fadeexp,
+                      uint32_t *diag, void *stream);
 
 /* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
  * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are OVERWRITTEN (every element is written; the
  * caller need not zero-fill them, unlike mvpraymarch.py:240-246).  With the forward's hand-off buffers the
  * primitive-centric kernel runs (no HBM atomics); primitives whose list overflowed primlist_cap, or everything
- * when the buffers are NULL / the slab exceeds the LDS budget, go through the ray-centric kernel with
- * global_atomic_add_f32. */
+ * when the buffers are NULL / the slab exceeds the LDS budget / a warp field is used (algo 1; grad_warp is then
+ * overwritten too), go through the ray-centric kernel with global_atomic_add_f32. */
 int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                        const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
-                       const float *primscale, int TD, int TH, int TW, const float *tplate, const float *raysat,
-                       const uint32_t *rayaux, uint32_t *primlist_count, const uint32_t *primlist,
-                       int primlist_cap, const float *grad_rayrgba, float *grad_primpos, float *grad_primrot,
-                       float *grad_primscale, float *grad_tplate, float fadescale, float fadeexp, uint32_t *diag,
-                       void *stream);
+                       const float *primscale, int TD, int TH, int TW, const float *tplate, int WD, int WH, int WW,
+                       const float *warp /*or NULL*/, const float *raysat, const uint32_t *rayaux,
+                       uint32_t *primlist_count, const uint32_t *primlist, int primlist_cap,
+                       const float *grad_rayrgba, float *grad_primpos, float *grad_primrot, float *grad_primscale,
+                       float *grad_tplate, float *grad_warp /*NULL iff warp is NULL*/, float fadescale,
+                       float fadeexp, uint32_t *diag, void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.mvp_abi_version() == 2
+    assert lib.mvp_abi_version() == 3
     assert b"bad argument" in lib.mvp_error_string(-1)
     assert lib.mvp_error_string(0) == b"ok"
 
@@ -58,16 +58,16 @@ def test_argument_validation_happens_before_any_device_work(lib):
     assert lib.mvp_aabb_build(1, -2, null, null, null, null, null) == -1
     assert lib.mvp_aabb_build(0, 8, null, null, null, null, null) == 0
     assert lib.mvp_aabb_build(1, 8, null, null, null, null, null) == -1
-    args = [1, 8, 8, 4, null, null, 0.1, null, null, null, null, null, 8, 8, 8, null, null, null, null, null, null, 0,
-            8.0, 8.0, null, null]
+    args = [1, 8, 8, 4, null, null, 0.1, null, null, null, null, null, 8, 8, 8, null, 0, 0, 0, null, null, null, null,
+            null, null, 0, 8.0, 8.0, null, null]
     assert lib.mvp_march_forward(*args) == -1              # null pointers
     args[0] = 0
     assert lib.mvp_march_forward(*args) == 0               # empty batch
     buf = (ctypes.c_float * 64)()
     p = ctypes.addressof(buf)
     p16 = (p + 15) & ~15
-    a = [1, 1, 1, 1, p16, p16, 0.0, p16, p16, p16, p16, p16, 8, 8, 8, p16, p16, None, None, None, None, 0, 8.0, 8.0,
-         None, None]
+    a = [1, 1, 1, 1, p16, p16, 0.0, p16, p16, p16, p16, p16, 8, 8, 8, p16, 0, 0, 0, None, p16, None, None, None, None,
+         0, 8.0, 8.0, None, None]
     assert lib.mvp_march_forward(*a) == -1                 # stepsize must be > 0
     a[6] = 0.1
     a[12] = 1
@@ -76,10 +76,13 @@ def test_argument_validation_happens_before_any_device_work(lib):
     a[15] = p16 + 4
     assert lib.mvp_march_forward(*a) == -1                 # misaligned template
     a[15] = p16
-    a[19] = p16                                            # primlist_count without primlist
+    a[23] = p16                                            # primlist_count without primlist
     assert lib.mvp_march_forward(*a) == -1
-    bw = [1, 8, 8, 4, null, null, 0.1, null, null, null, null, null, 8, 8, 8, null, null, null, null, null, 0,
-          null, null, null, null, null, 8.0, 8.0, null, null]
+    a[23] = None
+    a[16], a[19] = 1, p16                                  # warp grid dimension < 2
+    assert lib.mvp_march_forward(*a) == -2
+    bw = [1, 8, 8, 4, null, null, 0.1, null, null, null, null, null, 8, 8, 8, null, 0, 0, 0, null, null, null, null,
+          null, 0, null, null, null, null, null, null, 8.0, 8.0, null, null]
     assert lib.mvp_march_backward(*bw) == -1               # null pointers
     bw[3] = 0
     bw[4] = bw[5] = bw[7] = p16

@@ -43,7 +43,7 @@ BACKWARD_MODES = ["prim", "ray", "cap4"]  # primitive-centric | forced ray-centr
 
 
 def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, fadescale, fadeexp,
-           grad_out=None, mode="prim"):
+           grad_out=None, mode="prim", warp=None):
     """Run forward (+ backward with grad_out) through the public operator. Inputs: numpy float64/32.
     grad_out may be an array or a callable(raysat_numpy) -> array (evaluated after the forward).
     mode selects the backward implementation under test (all must agree with the oracle):
@@ -58,19 +58,22 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
     mm.keep_raysat = True
     t = dict(raypos=to_dev(raypos), raydir=to_dev(raydir), tminmax=to_dev(tminmax), primpos=to_dev(primpos),
              primrot=to_dev(primrot), primscale=to_dev(primscale), template=to_dev(template))
-    for k in ("primpos", "primrot", "primscale", "template"):
+    names = ("primpos", "primrot", "primscale", "template")
+    if warp is not None:
+        t["warp"] = to_dev(warp)
+        names = names + ("warp",)
+    for k in names:
         t[k].requires_grad_(grad_out is not None)
     with torch.set_grad_enabled(grad_out is not None):
         rgba = ops.mvpraymarch(t["raypos"], t["raydir"], float(stepsize), t["tminmax"],
-                               (t["primpos"], t["primrot"], t["primscale"]), t["template"], None,
-                               fadescale=float(fadescale), fadeexp=float(fadeexp))
+                               (t["primpos"], t["primrot"], t["primscale"]), t["template"], t.get("warp"),
+                               algo=1 if warp is not None else 0, fadescale=float(fadescale), fadeexp=float(fadeexp))
     grads = None
     if grad_out is not None:
         if callable(grad_out):
             grad_out = grad_out(npf(mm.last_raysat))
         rgba.backward(to_dev(grad_out))
-        grads = dict(primpos=npf(t["primpos"].grad), primrot=npf(t["primrot"].grad),
-                     primscale=npf(t["primscale"].grad), template=npf(t["template"].grad))
+        grads = {k: npf(t[k].grad) for k in names}
     torch.cuda.synchronize()
     d = mm.read_diag()
     mm.set_diag_buffer(None)
@@ -162,6 +165,63 @@ def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg, mode):
     assert np.abs(rgba[..., 3] - ref_rgba[..., 3]).max() <= FWD_TOL          # alpha agrees on fragile rays too
     ref = dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs)
     _check_grads(grads, ref, str(cfg))
+
+
+@pytest.mark.parametrize("name", ["march_warp_k8_m8", "march_warp_k8_m8_sat"])
+def test_warp_sampler_matches_reference_golden(ops, name):
+    """algo 1 (PrimSamplerTW<true>): fixtures from the reference's gradcheck(dowarp=True) dense loop (float64)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rgba, grads, diag = _march(ops, g["raypos"], g["raydir"], g["stepsize"], g["tminmax"], g["primpos"],
+                               g["primrot"], g["primscale"], g["template"], g["fadescale"], g["fadeexp"],
+                               grad_out=np.ones_like(g["rgba"]), warp=g["warp"])
+    assert np.abs(rgba - g["rgba"]).max() <= FWD_TOL * max(1.0, np.abs(g["rgba"]).max())
+    mine = dict(template=grads["template"] * g["chain_template"], primpos=grads["primpos"] * g["chain_primpos"],
+                primrot=grads["primrot"], primscale=grads["primscale"] * g["chain_primscale"])
+    ref = dict(template=g["graw_template"], primpos=g["graw_primpos"], primrot=g["graw_primrot"],
+               primscale=g["graw_primscale"])
+    _check_grads(mine, ref, name)
+    gw, rw = grads["warp"], g["graw_warp"]
+    assert cosine(gw, rw) >= POSE_COS and np.abs(gw - rw).max() <= POSE_TOL * np.abs(rw).max()
+
+
+def test_warp_sampler_matches_oracle_on_a_shell_scene(ops, oracle64):
+    """Warp field = identity grid + noise on a 4^3 grid, production fade, ragged image, K not a power of two."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 2, 45, 52, 300
+    s = make_scene(N, H, W, K, device="cpu", seed=21, alpha_gain=4.0)
+    g = torch.Generator().manual_seed(5)
+    lin = torch.linspace(-1.0, 1.0, 4)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    ident = torch.stack([xx, yy, zz], dim=-1)                                  # warp[z,y,x] = (x,y,z): identity
+    warp = (ident[None, None] + 0.15 * torch.randn(N, K, 4, 4, 4, 3, generator=g)).contiguous().numpy()
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(),
+         s["template"].numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, warp=warp)
+    gout = np.random.default_rng(8).normal(size=ref_rgba.shape)
+    fragile = {}
+
+    def masked(hip_sat):
+        fragile["m"] = np.abs(hip_sat - ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(ref_sat).max())
+        g2 = gout.copy()
+        g2[fragile["m"]] = 0.0
+        return g2
+
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=masked, warp=warp)
+    fr = fragile["m"]
+    assert fr.sum() <= max(2, 0.005 * fr.size)
+    g2 = gout.copy()
+    g2[fr] = 0.0
+    rgp, rgr, rgs, rgt, rgw = oracle64.march_backward(*a, ref_sat, g2, warp=warp)
+    err = np.abs(rgba - ref_rgba).max(-1)
+    assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "warp scene")
+    # grad_warp is a scatter of dL/dy1 (a position gradient: white-noise slabs make it cancel heavily, like the pose
+    # gradients); held to cosine >= 0.9999, norm-wise 1e-2 and max-abs 1e-1 (see tests/test_gpu_fullsize.py for the
+    # calibration of these bounds with the float32 build of the oracle)
+    gw = grads["warp"]
+    stats = (cosine(gw, rgw), np.linalg.norm(gw - rgw) / np.linalg.norm(rgw), np.abs(gw - rgw).max() / np.abs(rgw).max())
+    assert stats[0] >= POSE_COS and stats[1] <= 1e-2 and stats[2] <= 1e-1, stats
 
 
 def test_heavy_scene_takes_the_exact_traversal_fallback(ops, oracle64):
@@ -289,8 +349,10 @@ def test_operator_errors(ops):
         ops.mvpraymarch(rp, rd, s["stepsize"], tm, prim, s["template"].permute(0, 1, 2, 3, 5, 4), None)
     with pytest.raises(NotImplementedError):
         ops.mvpraymarch(rp, rd, s["stepsize"], tm, prim, s["template"], None, usebvh=True)
+    with pytest.raises(RuntimeError):
+        ops.mvpraymarch(rp, rd, s["stepsize"], tm, prim, s["template"], None, algo=1)      # algo 1 needs a warp field
     with pytest.raises(NotImplementedError):
-        ops.mvpraymarch(rp, rd, s["stepsize"], tm, prim, s["template"], None, algo=1)
+        ops.mvpraymarch(rp, rd, s["stepsize"], tm, prim, s["template"], None, algo=2)
     # packed [N,K,5,3] primtransf (mvpraymarch.py:355-360) and chlast=False give the same image
     packed = torch.cat([s["primpos"][:, :, None], s["primrot"], s["primscale"][:, :, None]], dim=2).contiguous()
     a = ops.mvpraymarch(rp, rd, s["stepsize"], tm, prim, s["template"], None)
