@@ -1566,7 +1566,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     int rc = march_common_checks(true, p);
     if (rc == 1) rc = MVP_OK;  // no rays: the gradients are still defined (all zero) -> fall through to the fill
     if (rc != MVP_OK) return rc;
-    if (K == 0) return MVP_OK;
+    if (K == 0 || N == 0) return MVP_OK;  // empty gradient tensors: nothing to write
     if (!grad_primpos || !grad_primrot || !grad_primscale || !grad_tplate) return MVP_ERR_BADARG;
     if (!aligned16(grad_tplate)) return MVP_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;

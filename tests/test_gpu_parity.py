@@ -263,6 +263,57 @@ def test_no_grad_mode_and_empty_rays(ops):
     assert torch.count_nonzero(z) == 0
 
 
+def test_degenerate_shapes(ops):
+    """Empty batch, single-pixel image, zero-height image: shapes come back right and nothing is launched out of
+    bounds (the reference's launchers would be handed grid dimension 0)."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(2, 8, 8, 16, device="cuda", seed=2)
+    prim = (s["primpos"], s["primrot"], s["primscale"])
+    for n, h, w in [(0, 8, 8), (2, 1, 1), (2, 0, 8), (2, 3, 0)]:
+        sl = slice(0, n)
+        pc = s["pixelcoords"][sl, :h, :w].contiguous()
+        rp, rd, tm = ops.compute_raydirs(s["campos"][sl], s["camrot"][sl], s["focal"][sl], s["princpt"][sl], pc, 256.0)
+        assert rp.shape == (n, h, w, 3) and tm.shape == (n, h, w, 2)
+        t = s["template"][sl].clone().requires_grad_(True)
+        out = ops.mvpraymarch(rp, rd, s["stepsize"], tm, tuple(x[sl] for x in prim), t, None)
+        assert out.shape == (n, h, w, 4)
+        out.sum().backward()
+        assert t.grad.shape == t.shape and torch.isfinite(t.grad).all()
+        if n * h * w == 0:
+            assert float(t.grad.abs().sum()) == 0.0
+
+
+def test_very_fine_steps_use_the_unpacked_path(ops, oracle64):
+    """stepsize so small that lattice-step indices exceed the packed 16-bit ranges / 23-bit sample keys: the forward
+    falls back to unranged sweeping and raises the global flag, so the backward must come from the ray-centric kernel."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(1, 8, 8, 4, device="cpu", seed=12, alpha_gain=0.01)   # faint: nothing saturates early
+    s["primscale"] = s["primscale"] * 0.2
+    dt = 2.0e-5                                   # ~1e5 steps across the volume
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, dt, tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
+    ref, ref_sat, st = oracle64.march_forward(*a)
+    assert st["steps"] / max(1, st["rays_hit"]) > 65535     # more lattice steps per ray than the packed ranges hold
+    gout = np.random.default_rng(2).normal(size=ref.shape)
+    fragile = {}
+
+    def masked(hip_sat):
+        fragile["m"] = np.abs(hip_sat - ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(ref_sat).max())
+        g2 = gout.copy()
+        g2[fragile["m"]] = 0.0
+        return g2
+
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=masked)
+    g2 = gout.copy()
+    g2[fragile["m"]] = 0.0
+    rg = dict(zip(("primpos", "primrot", "primscale", "template"), oracle64.march_backward(*a, ref_sat, g2)))
+    # 1e5 accumulated fp32 samples per ray: forward tolerance scaled by sqrt(steps / 150)
+    assert np.abs(rgba - ref)[~fragile["m"]].max() <= 30 * FWD_TOL * max(1.0, np.abs(ref).max())
+    assert np.abs(grads["template"] - rg["template"]).max() <= 3e-2 * np.abs(rg["template"]).max()
+    for k in ("primpos", "primrot", "primscale"):
+        assert cosine(grads[k], rg[k]) >= 0.999, k
+
+
 def test_raydirs_matches_golden_and_oracle(ops, oracle64):
     g = np.load(os.path.join(GOLDEN, "raydirs_small.npz"))
     out = ops.compute_raydirs(to_dev(g["viewpos"]), to_dev(g["viewrot"]), to_dev(g["focal"]), to_dev(g["princpt"]),
