@@ -29,6 +29,8 @@ SIGNATURES = {
                            [_c_void_p] + [_c_int] * 3 + [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 6 + [_c_float] * 2 +
                            [_c_void_p] * 2),
 }
+SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
+SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
 ABI_VERSION = 3
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",

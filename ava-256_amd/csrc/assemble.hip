@@ -1,0 +1,137 @@
+// assemble.hip -- decoder -> raymarch hand-off: builds the channels-last RGBA slab tensor the march reads directly
+// from the two conv-decoder outputs, in one pass.
+//
+// What it replaces in the reference (three separate places, ~4 full passes over a 134 MB/image tensor in eager PyTorch):
+//   models/decoders/rgb.py:137-143        rgb.view(N, B, 3, h, B, w, B).permute(0,3,5,1,4,6,2).reshape(N, h*w, B,B,B, 3)
+//   models/decoders/geometry.py:183-185   the same with 1 channel for the opacity
+//   models/decoders/assembler.py:261      template = cat([relu(rgb * 25 + 100), relu(alpha)], dim=-1)
+// i.e.  tplate[n, hy*nh + wx, z, y, x, c] = relu(tex[n, z*3 + c, hy*B + y, wx*B + x] * 25 + 100)   (c < 3)
+//       tplate[n, hy*nh + wx, z, y, x, 3] = relu(opacity[n, z, hy*B + y, wx*B + x])
+// Pure data movement: HBM-bound, 32 B read + 32 B written per voxel... per 2 voxels: 16 B/voxel each way.
+//
+// Mapping for CDNA4: a thread owns 4 consecutive x of one (n, z, image row): four 16-byte loads (three tex planes and
+// the opacity plane; a wave reads 1 KiB contiguous per plane) and four 16-byte stores that form 64 contiguous bytes
+// of the slab row; two neighbouring lanes complete a 128-byte line.  No LDS, no atomics.
+// The products use separate multiply and add (no FMA contraction) so that the result is bit-identical to the eager
+// PyTorch expression.
+#include "mvp_device.h"
+#include "mvp_host.h"
+
+namespace mvp {
+
+__device__ __forceinline__ float relu_keep_nan(float v) { return v <= 0.f ? 0.f : v; }  // NaN stays NaN like torch.relu
+
+// rgb * 25 + 100 with TWO roundings, as the eager expression computes it (hipcc contracts a*b+c to an FMA by default,
+// also through __fmul_rn/__fadd_rn, which are plain operators in HIP)
+__device__ __forceinline__ float rgb_denorm(float v) {
+#pragma clang fp contract(off)
+    const float m = v * 25.0f;
+    return m + 100.0f;
+}
+
+__global__ __launch_bounds__(256) void assemble_fwd_kernel(int N, int nh, int B, const float *__restrict__ tex,
+                                                           const float *__restrict__ opac,
+                                                           float *__restrict__ tplate) {
+    const int S = nh * B, S4 = S >> 2;
+    const long long total = (long long)N * B * S * S4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int X4 = (int)(i % S4);
+        long long r = i / S4;
+        const int R = (int)(r % S);
+        r /= S;
+        const int z = (int)(r % B), n = (int)(r / B);
+        const int X = X4 << 2;
+        const size_t plane = (size_t)S * S, rowoff = (size_t)R * S + X;
+        const float *tp = tex + ((size_t)n * 3 * B + (size_t)z * 3) * plane + rowoff;
+        const float4 r4 = *reinterpret_cast<const float4 *>(tp);
+        const float4 g4 = *reinterpret_cast<const float4 *>(tp + plane);
+        const float4 b4 = *reinterpret_cast<const float4 *>(tp + 2 * plane);
+        const float4 a4 = *reinterpret_cast<const float4 *>(opac + ((size_t)n * B + z) * plane + rowoff);
+        const int hy = R / B, y = R - hy * B, wx = X / B, x = X - wx * B;
+        float4 *out = reinterpret_cast<float4 *>(tplate) +
+                      ((((size_t)n * nh * nh + (size_t)hy * nh + wx) * B + z) * B + y) * B + x;
+#define MVP_RGB(V_) relu_keep_nan(rgb_denorm(V_))
+        out[0] = make_float4(MVP_RGB(r4.x), MVP_RGB(g4.x), MVP_RGB(b4.x), relu_keep_nan(a4.x));
+        out[1] = make_float4(MVP_RGB(r4.y), MVP_RGB(g4.y), MVP_RGB(b4.y), relu_keep_nan(a4.y));
+        out[2] = make_float4(MVP_RGB(r4.z), MVP_RGB(g4.z), MVP_RGB(b4.z), relu_keep_nan(a4.z));
+        out[3] = make_float4(MVP_RGB(r4.w), MVP_RGB(g4.w), MVP_RGB(b4.w), relu_keep_nan(a4.w));
+#undef MVP_RGB
+    }
+}
+
+// grad_tex = 25 * g_rgb * [tplate_rgb > 0], grad_opacity = g_a * [tplate_a > 0]  (relu'(u) = [relu(u) > 0], as torch)
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(int N, int nh, int B, const float *__restrict__ tplate,
+                                                           const float *__restrict__ gtpl,
+                                                           float *__restrict__ gtex, float *__restrict__ gopac) {
+    const int S = nh * B, S4 = S >> 2;
+    const long long total = (long long)N * B * S * S4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int X4 = (int)(i % S4);
+        long long r = i / S4;
+        const int R = (int)(r % S);
+        r /= S;
+        const int z = (int)(r % B), n = (int)(r / B);
+        const int X = X4 << 2;
+        const size_t plane = (size_t)S * S, rowoff = (size_t)R * S + X;
+        const int hy = R / B, y = R - hy * B, wx = X / B, x = X - wx * B;
+        const size_t vo = ((((size_t)n * nh * nh + (size_t)hy * nh + wx) * B + z) * B + y) * B + x;
+        const float4 *o = reinterpret_cast<const float4 *>(tplate) + vo;
+        const float4 *g = reinterpret_cast<const float4 *>(gtpl) + vo;
+        float rr[4], gg[4], bb[4], aa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 ov = o[j], gv = g[j];
+            rr[j] = ov.x > 0.f ? gv.x * 25.0f : 0.f;
+            gg[j] = ov.y > 0.f ? gv.y * 25.0f : 0.f;
+            bb[j] = ov.z > 0.f ? gv.z * 25.0f : 0.f;
+            aa[j] = ov.w > 0.f ? gv.w : 0.f;
+        }
+        float *tp = gtex + ((size_t)n * 3 * B + (size_t)z * 3) * plane + rowoff;
+        *reinterpret_cast<float4 *>(tp) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        *reinterpret_cast<float4 *>(tp + plane) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+        *reinterpret_cast<float4 *>(tp + 2 * plane) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        *reinterpret_cast<float4 *>(gopac + ((size_t)n * B + z) * plane + rowoff) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+    }
+}
+
+static int assemble_args_ok(int N, int nh, int B) {
+    if (N < 0 || nh < 0 || B < 0) return MVP_ERR_BADARG;
+    if (B % 4 != 0 && (long long)N * nh * B != 0) return MVP_ERR_UNSUPPORTED;  // 16-byte path needs 4 | B
+    return MVP_OK;
+}
+
+}  // namespace mvp
+
+extern "C" int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const float *opacity,
+                                             float *tplate, void *stream) {
+    using namespace mvp;
+    int rc = assemble_args_ok(N, nh, B);
+    if (rc != MVP_OK) return rc;
+    const long long S = (long long)nh * B, total = (long long)N * B * S * (S / 4);
+    if (total == 0) return MVP_OK;
+    if (!tex || !opacity || !tplate || !aligned16(tex) || !aligned16(opacity) || !aligned16(tplate)) return MVP_ERR_BADARG;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(assemble_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, N, nh, B, tex,
+                       opacity, tplate);
+    return launch_status();
+}
+
+extern "C" int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
+                                              float *grad_tex, float *grad_opacity, void *stream) {
+    using namespace mvp;
+    int rc = assemble_args_ok(N, nh, B);
+    if (rc != MVP_OK) return rc;
+    const long long S = (long long)nh * B, total = (long long)N * B * S * (S / 4);
+    if (total == 0) return MVP_OK;
+    if (!tplate || !grad_tplate || !grad_tex || !grad_opacity || !aligned16(tplate) || !aligned16(grad_tplate) ||
+        !aligned16(grad_tex) || !aligned16(grad_opacity))
+        return MVP_ERR_BADARG;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, N, nh, B, tplate,
+                       grad_tplate, grad_tex, grad_opacity);
+    return launch_status();
+}

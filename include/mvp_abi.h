@@ -110,6 +110,17 @@ int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const fl
                        float *grad_tplate, float *grad_warp /*NULL iff warp is NULL*/, float fadescale,
                        float fadeexp, uint32_t *diag, void *stream);
 
+/* Decoder -> raymarch hand-off (no counterpart in the reference's extensions: there it is eager PyTorch spread over
+ * models/decoders/rgb.py:137-143, models/decoders/geometry.py:183-185 and models/decoders/assembler.py:261).
+ *   tex     [N, 3*B, nh*B, nh*B]  RGB decoder output (conv output + bias), channel index = z*3 + c
+ *   opacity [N,   B, nh*B, nh*B]  geometry decoder opacity, channel index = z
+ *   tplate  [N, nh*nh, B, B, B, 4] = cat(relu(rgb*25+100), relu(opacity)) in the march's channels-last slab layout
+ * One pass, bit-identical to the eager expression.  Backward: grad_tex / grad_opacity are fully written. */
+int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const float *opacity, float *tplate,
+                                  void *stream);
+int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
+                                   float *grad_tex, float *grad_opacity, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,55 @@ def save_raydirs(name, N=2, H=12, W=20, volradius=1.0):
     print(name, "written")
 
 
+def save_assemble_map(name="assemble_map", nsample=40000):
+    """Read the decoder -> slab layout mapping off the reference's REAL decoder modules (models/decoders/rgb.py,
+    geometry.py) at the shipped size (nboxes 128^2, boxsize 8, imsize 1024): a forward hook replaces the last
+    conv layer's output by an index-encoded tensor (float64), the module then applies its own view/permute/reshape
+    (and exp(0.1*x) for the opacity), and the output is decoded back into (destination, source) flat-index pairs."""
+    # the reference's `models` is a namespace package (no __init__.py); this repository's import-path shim
+    # `models/__init__.py` would win the lookup, so take the repository root off sys.path while importing
+    repo_root = os.path.dirname(os.path.dirname(OUT))
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [q for q in sys.path if os.path.abspath(q or os.getcwd()) != repo_root]
+    for m in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+        del sys.modules[m]
+    from models.decoders.rgb import RGBDecoder
+    from models.decoders.geometry import GeometryDecoder
+    sys.path[:] = saved
+    torch.manual_seed(0)
+    nh, B, S = 128, 8, 1024
+    chs = [256, 128, 128, 64, 64, 32, 16, 3]
+    idb = [torch.zeros(1, chs[i], 8 * 2 ** i, 8 * 2 ** i, dtype=torch.float64) for i in range(8)]
+    code = lambda: torch.randn(1, 16, 4, 4, dtype=torch.float64)
+    rng = np.random.default_rng(0)
+    out = {}
+    # ---- RGB: tex value = its own flat index (exact in float64) ----
+    dec = RGBDecoder(imsize=S, nboxes=nh * nh, boxsize=B, outch=3, viewcond=True).double()
+    enc = torch.arange(3 * B * S * S, dtype=torch.float64).view(1, 3 * B, S, S)
+    dec.layers["t7"].register_forward_hook(lambda m, i, o: enc)
+    with torch.no_grad():
+        rgb = dec(code(), code(), idb, torch.randn(1, 3, dtype=torch.float64))          # [1,K,8,8,8,3]
+    flat = rgb.reshape(-1).numpy()
+    dst = rng.integers(0, flat.size, nsample)
+    out["rgb_dst"], out["rgb_src"] = dst.astype(np.int64), np.rint(flat[dst]).astype(np.int64)
+    # ---- opacity = exp((x + 0) * 0.1): x = 10*log(index + 1) decodes to index + 1 ----
+    nv = 12
+    uv = rng.random((30, 2)).astype(np.float32)
+    geo = GeometryDecoder(uv, rng.integers(0, nv, (20, 3)), rng.integers(0, 30, (20, 3)), nvtx=nv, motion_size=128,
+                          geo_size=256, imsize=S, nboxes=nh * nh, boxsize=B).double()
+    enc_o = (10.0 * torch.log(torch.arange(B * S * S, dtype=torch.float64) + 1.0)).view(1, B, S, S)
+    last = list(geo.layers.keys())[-1]
+    geo.layers[last].register_forward_hook(lambda m, i, o: enc_o)
+    with torch.no_grad():
+        opac = geo(code(), code(), idb)[0]                                                 # [1,K,8,8,8,1]
+    flat = opac.reshape(-1).numpy()
+    dst = rng.integers(0, flat.size, nsample)
+    out["op_dst"], out["op_src"] = dst.astype(np.int64), (np.rint(flat[dst]) - 1).astype(np.int64)
+    out["nh"], out["B"] = np.int64(nh), np.int64(B)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "written:", nsample, "pairs each;", os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024, "KB")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
     # reference __main__ settings (mvpraymarch.py:749-761): fadescale 6.5, fadeexp 7.5
@@ -161,3 +210,4 @@ if __name__ == "__main__":
     save_march("march_warp_k8_m8_sat", N=1, H=13, W=13, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0,
                dowarp=True)
     save_raydirs("raydirs_small")
+    save_assemble_map()

@@ -1,0 +1,65 @@
+"""Decoder -> raymarch hand-off (row N2): the numpy oracle is pinned to the layout the reference's real decoder modules
+produce (tests/golden/assemble_map.npz), and the gfx950 kernel must equal the oracle BIT FOR BIT (pure data movement +
+one multiply, one add, one max per element); its backward must equal autograd of the eager expression."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def test_oracle_layout_matches_the_reference_modules():
+    from oracle import assemble_oracle as ao
+    g = np.load(os.path.join(GOLDEN, "assemble_map.npz"))
+    nh, B = int(g["nh"]), int(g["B"])
+    d = g["rgb_dst"]                                     # flat index into [K,B,B,B,3]
+    c = d % 3; x = (d // 3) % B; y = (d // (3 * B)) % B; z = (d // (3 * B * B)) % B; k = d // (3 * B ** 3)
+    assert np.array_equal(ao.src_index_rgb(nh, B, k, z, y, x, c), g["rgb_src"])
+    d = g["op_dst"]                                      # flat index into [K,B,B,B,1]
+    x = d % B; y = (d // B) % B; z = (d // (B * B)) % B; k = d // (B ** 3)
+    assert np.array_equal(ao.src_index_opacity(nh, B, k, z, y, x), g["op_src"])
+    # the vectorised restatement agrees with the index functions (small config, every element)
+    nh, B, N = 3, 4, 2
+    S = nh * B
+    rng = np.random.default_rng(1)
+    tex = rng.normal(size=(N, 3 * B, S, S)).astype(np.float32)
+    op = rng.normal(size=(N, B, S, S)).astype(np.float32)
+    out = ao.assemble_template(tex, op, nh * nh, B)
+    assert out.shape == (N, nh * nh, B, B, B, 4) and out.dtype == np.float32
+    for n in range(N):
+        for k in range(nh * nh):
+            for z in range(B):
+                for y in range(B):
+                    for x in range(B):
+                        for c in range(3):
+                            v = tex[n].reshape(-1)[ao.src_index_rgb(nh, B, k, z, y, x, c)]
+                            assert out[n, k, z, y, x, c] == max(np.float32(v * np.float32(25)) + np.float32(100), 0)
+                        v = op[n].reshape(-1)[ao.src_index_opacity(nh, B, k, z, y, x)]
+                        assert out[n, k, z, y, x, 3] == max(v, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 3, 4), (1, 16, 8), (1, 128, 8)], ids=lambda c: "N%d_nh%d_B%d" % c)
+def test_kernel_bit_exact_and_backward(cfg):
+    from ava256_amd.assemble import assemble_template
+    from oracle import assemble_oracle as ao
+    N, nh, B = cfg
+    S = nh * B
+    g = torch.Generator(device="cuda").manual_seed(3)
+    tex = (torch.randn(N, 3 * B, S, S, device="cuda", generator=g) * 2.0 - 3.5).requires_grad_(True)   # ~half below -4
+    op = (torch.randn(N, B, S, S, device="cuda", generator=g)).requires_grad_(True)
+    out = assemble_template(tex, op, nh * nh, B)
+    ref = ao.assemble_template(tex.detach().cpu().numpy(), op.detach().cpu().numpy(), nh * nh, B)
+    assert np.array_equal(out.detach().cpu().numpy(), ref)
+    gout = torch.randn(out.shape, device="cuda", generator=g)
+    out.backward(gout)
+    # eager PyTorch statement of the same thing (rgb.py:137-143, geometry.py:183-185, assembler.py:261)
+    t2, o2 = tex.detach().clone().requires_grad_(True), op.detach().clone().requires_grad_(True)
+    rgb = t2.view(N, B, 3, nh, B, nh, B).permute(0, 3, 5, 1, 4, 6, 2).reshape(N, nh * nh, B, B, B, 3)
+    a = o2.view(N, B, 1, nh, B, nh, B).permute(0, 3, 5, 1, 4, 6, 2).reshape(N, nh * nh, B, B, B, 1)
+    eager = torch.cat([torch.relu(rgb * 25.0 + 100.0), torch.relu(a)], dim=-1)
+    assert torch.equal(eager, out.detach())
+    eager.backward(gout)
+    assert torch.equal(t2.grad, tex.grad) and torch.equal(o2.grad, op.grad)
