@@ -965,6 +965,13 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         }
     }
 
+    if (!BWD && p.pl_count != nullptr) {
+        // max |raysat| over the packet -> tail word [2] (the backward's fixed-point bound); |-1| = 1 when unsaturated
+        float m = inimg ? fmaxf(fabsf(raysat.x), fmaxf(fabsf(raysat.y), fabsf(raysat.z))) : 0.f;
+        if (!(m == m)) m = INFINITY;
+        m = wave_max(m);
+        if (lane == 0) atomicMax(p.pl_count + (size_t)p.N * K + 2, __float_as_uint(m));
+    }
     if (!BWD && inimg) {
         reinterpret_cast<float4 *>(p.rayrgba)[r] = rgba;  // primaccum.h:51-56
         if (p.raysat) st3(p.raysat + r * 3, raysat);
@@ -1034,27 +1041,19 @@ constexpr int kQueueCap = 512;      // rays per round: 8 entries x 64 lanes
 constexpr int kEntriesPerRound = 8;  // two per wave
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
 
-// G = max |grad_rayrgba|, Rmax = max |raysat| -> out[0], out[1] (float bits; non-negative floats order like uints)
-__global__ __launch_bounds__(256) void absmax2_kernel(const float4 *__restrict__ g4, size_t n4,
-                                                      const float *__restrict__ rs, size_t n3,
-                                                      uint32_t *__restrict__ out) {
-    float m0 = 0.f, m1 = 0.f;
+// G = max |grad_rayrgba| -> out[0] (float bits; non-negative floats order like uints).  max |raysat| (out[1]) is
+// produced by the forward kernel itself.
+__global__ __launch_bounds__(256) void absmax_kernel(const float4 *__restrict__ g4, size_t n4,
+                                                     uint32_t *__restrict__ out) {
+    float m0 = 0.f;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = g4[i];
         m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         if (!(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w)) m0 = INFINITY;  // NaN is sticky
     }
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += stride) {
-        const float v = rs[i];
-        m1 = (v == v) ? fmaxf(m1, fabsf(v)) : INFINITY;
-    }
     m0 = wave_max(m0);
-    m1 = wave_max(m1);
-    if (lane_id() == 0) {
-        atomicMax(out + 0, __float_as_uint(m0));
-        atomicMax(out + 1, __float_as_uint(m1));
-    }
+    if (lane_id() == 0) atomicMax(out, __float_as_uint(m0));
 }
 
 // largest power of two s with B * s < 2^kFixHiBits (B finite, normal, > 0)
@@ -1592,10 +1591,11 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     } else {
         const long long pb = 8ll * ((K + 7) / 8) * N;
         if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
-        // bounds for the fixed-point scales: max |grad_rayrgba| and max |raysat| into the tail of primlist_count
-        hipLaunchKernelGGL(absmax2_kernel, dim3(256 * 8), dim3(256), 0, st,
-                           reinterpret_cast<const float4 *>(grad_rayrgba), (size_t)N * H * W, raysat,
-                           (size_t)N * H * W * 3, p.pl_count + (size_t)N * K + 1);
+        // bound for the fixed-point scales: max |grad_rayrgba| into the tail of primlist_count (max |raysat| is there
+        // already, written by the forward)
+        hipLaunchKernelGGL(absmax_kernel, dim3(256 * 8), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(grad_rayrgba), (size_t)N * H * W,
+                           p.pl_count + (size_t)N * K + 1);
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         const dim3 grid((unsigned)pb), block(kPrimBlock);
