@@ -6,7 +6,7 @@ TAG=$1; shift
 CTRS=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=/tmp/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT gpurun_out/$TAG
-timeout 900 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -o $TAG -- python bench.py "$@" > gpurun_out/$TAG/bench.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT -o $TAG -- python bench.py "$@" > gpurun_out/$TAG/bench.log 2>&1
 CSV=$(find $OUT -name "*counter_collection.csv" | head -1)
 python - "$CSV" gpurun_out/$TAG/pmc_summary.csv <<'PY'
 import csv, sys, collections

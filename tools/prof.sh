@@ -5,7 +5,7 @@ set -u
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=/tmp/prof_$TAG; rm -rf $OUT; mkdir -p $OUT gpurun_out/$TAG
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python bench.py "$@" > gpurun_out/$TAG/bench.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python bench.py "$@" > gpurun_out/$TAG/bench.log 2>&1
 find $OUT -name "*kernel_stats.csv" -exec cp {} gpurun_out/$TAG/ \;
 tail -1 gpurun_out/$TAG/bench.log | cut -c1-400
 python - gpurun_out/$TAG/${TAG}_kernel_stats.csv <<'PY'
