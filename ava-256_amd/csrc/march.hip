@@ -841,21 +841,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                               c101.w * w101 + c110.w * w110 + c111.w * w111;
                         const float alpha = v.w * fade;  // primsampler.h:63
 
-                        if (!BWD) {
-                            // ---- primaccum.h:63-79 ----
-                            const float newalpha = rgba.w + alpha * dt;
-                            const float contrib = fminf(newalpha, 1.f) - rgba.w;
-                            rgba.x += v.x * contrib;
-                            rgba.y += v.y * contrib;
-                            rgba.z += v.z * contrib;
-                            rgba.w += contrib;
-                            if (newalpha >= 1.f) {
-                                raysat = mk3(v.x, v.y, v.z);  // first (and only) time: sat stops further samples
-                                sat = true;
-                                satkey = ((uint32_t)s << 9) | (uint32_t)(ch * kWave + bit);
-                                wbefore = rgba.w - contrib;
-                            }
-                        } else {
+                        {  // (only the backward instantiation reaches this body; the forward left through pass B above)
                             // ---- primaccum.h:81-98 ----
                             const float a = alpha * dt;
                             const bool thissat = rgba.w + a >= 1.f;
@@ -1141,10 +1127,23 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         if (tid < 3) p.grad_primpos[pk * 3 + tid] = 0.f;
         return;
     }
-    const Rec q = rec_from_global(p.primpos + (size_t)n * K * 3, p.primrot + (size_t)n * K * 9,
-                                  p.primscale + (size_t)n * K * 3, k);
+    Rec q = rec_from_global(p.primpos + (size_t)n * K * 3, p.primrot + (size_t)n * K * 9,
+                            p.primscale + (size_t)n * K * 3, k);
+    // block-uniform, but loaded with vector loads (the kernel also stores, so the compiler will not use s_load):
+    // move the 15 words to SGPRs
+    q.pos = mk3(uni(q.pos.x), uni(q.pos.y), uni(q.pos.z));
+    q.r0 = mk3(uni(q.r0.x), uni(q.r0.y), uni(q.r0.z));
+    q.r1 = mk3(uni(q.r1.x), uni(q.r1.y), uni(q.r1.z));
+    q.r2 = mk3(uni(q.r2.x), uni(q.r2.y), uni(q.r2.z));
+    q.scale = mk3(uni(q.scale.x), uni(q.scale.y), uni(q.scale.z));
 
     const float dt = p.stepsize;
+    // per-image base pointers are wave-uniform (SGPR pairs); rays are addressed with a 32-bit index inside the image,
+    // so every per-lane load is "scalar base + 32-bit vector offset" instead of a 64-bit address held in two VGPRs
+    const size_t img = (size_t)n * p.H * p.W;
+    const float *raypos_n = p.raypos + img * 3, *raydir_n = p.raydir + img * 3, *tminmax_n = p.tminmax + img * 2;
+    const float *grad_n = p.grad_rayrgba + img * 4, *raysat_n = p.raysat_in + img * 3;
+    const uint32_t *aux_n = p.rayaux + img * 4;
     const int sW = 1, sH = p.TW, sD = p.TH * p.TW;  // voxel strides of the template slab
     const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -1156,6 +1155,12 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         if (tid < kLenBuckets) s_bucket[tid] = 0u;
         if (tid == 0) s_qn[1] = 0u;
         __syncthreads();
+        // The transform is block-uniform and lives in SGPRs.  Made opaque once per round, so that packed-math operand
+        // pairs built from it are re-made here (a v_mov each) instead of being carried, spilled, across the march.
+        asm volatile("; round-local transform"
+                     : "+s"(q.pos.x), "+s"(q.pos.y), "+s"(q.pos.z), "+s"(q.r0.x), "+s"(q.r0.y), "+s"(q.r0.z),
+                       "+s"(q.r1.x), "+s"(q.r1.y), "+s"(q.r1.z), "+s"(q.r2.x), "+s"(q.r2.y), "+s"(q.r2.z),
+                       "+s"(q.scale.x), "+s"(q.scale.y), "+s"(q.scale.z));
         // ---------------- phase 1: which rays of these packets cross the box, and over which steps ----------------
         // Each wave owns up to two entries of the round; a live ray takes a ticket in the bucket of its step count
         // (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the
@@ -1180,12 +1185,13 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                 const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
                 const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
                 const bool inimg = px < p.W && py < p.H;
-                const size_t r = ((size_t)n * p.H + (inimg ? py : 0)) * p.W + (inimg ? px : 0);
+                const uint32_t r = inimg ? (uint32_t)py * (uint32_t)p.W + (uint32_t)px : 0u;  // index inside image n
                 int slo = 1, shi = 0;
                 if (inimg) {
-                    const f3 o = ld3(p.raypos + r * 3), d = ld3(p.raydir + r * 3);
-                    const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
-                    const int incs = (int)p.rayaux[r * 4 + 2];
+                    // byte offsets computed in 32 bits: "SGPR base + zero-extended VGPR offset" addressing
+                    const f3 o = ld3(at_bytes<float>(raypos_n, r * 12u)), d = ld3(at_bytes<float>(raydir_n, r * 12u));
+                    const float2 tt = *at_bytes<float2>(tminmax_n, r * 8u);
+                    const int incs = (int)*at_bytes<uint32_t>(aux_n, r * 16u + 8u);
                     // the same formulas the forward used for the packet range [elo, ehi] (the union of these over lanes)
                     const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
                     const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
@@ -1205,7 +1211,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     const int len = shi - slo + 1;
                     if (len > 127) toolong = true;
                     live2[u] = true;
-                    item[u] = make_uint4((uint32_t)r, (uint32_t)slo | ((uint32_t)len << 16), slot, 0u);
+                    item[u] = make_uint4(r, (uint32_t)slo | ((uint32_t)len << 16), slot, 0u);
                     ticket[u] = atomicAdd(s_bucket + min(len, kLenBuckets) - 1, 1u);
                     mylen += (uint32_t)len;
                 }
@@ -1222,10 +1228,16 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                 p.pl_count[pk] = 0xffffffffu;
                 atomicOr(tail, kFlagListOverflow);
             }
-            for (int v = tid; v < V; v += kPrimBlock) gT4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid < 9) p.grad_primrot[pk * 9 + tid] = 0.f;
-            if (tid < 3) p.grad_primscale[pk * 3 + tid] = 0.f;
-            if (tid < 3) p.grad_primpos[pk * 3 + tid] = 0.f;
+            // (addresses re-derived from a laundered pk: this exit sits inside the march loop and would otherwise keep
+            //  the output pointers of the zero-fill live -- and spilled -- through the whole loop)
+            size_t pkz = pk;
+            int tz = tid;
+            asm volatile("; zero-fill exit" : "+s"(pkz), "+v"(tz));
+            float4 *gz = reinterpret_cast<float4 *>(p.grad_tplate) + pkz * (size_t)V;
+            for (int v = tz; v < V; v += kPrimBlock) gz[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tz < 9) p.grad_primrot[pkz * 9 + tz] = 0.f;
+            if (tz < 3) p.grad_primscale[pkz * 3 + tz] = 0.f;
+            if (tz < 3) p.grad_primpos[pkz * 3 + tz] = 0.f;
             return;
         }
         if (tid == 0) {  // exclusive prefix over the buckets, longest rays first
@@ -1246,7 +1258,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         const uint32_t round_samples = s_qn[1];
         if (pending + round_samples > kFixMaxSamples) {
             const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
-            for (int v = tid; v < 4 * Vp; v += kPrimBlock) {
+            int td = tid;
+            asm volatile("; drain addresses are made here" : "+v"(td));
+            for (int v = td; v < 4 * Vp; v += kPrimBlock) {
                 const float inv = v < 3 * Vp ? i_rgb : i_a;
                 s_gf[v] += ((float)s_hi[v] * 65536.f + (float)s_lo[v]) * inv;
                 s_hi[v] = 0;
@@ -1265,7 +1279,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             const int ql = ((lane & 31) << 1) | (lane >> 5);
             const bool have = ql < per && qb + ql < nq;
             const uint4 it = have ? s_q[qb + ql] : make_uint4(0u, 0u, 0u, 0u);
-            const size_t r = it.x;
+            const uint32_t r = it.x;  // index inside image n
             const int slo = (int)(it.y & 0xffffu), len = have ? (int)(it.y >> 16) : 0;
             const uint32_t slot = it.z;
             f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
@@ -1274,14 +1288,14 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             float dLw = 0.f, wbefore = 0.f, tend = -INFINITY;
             uint32_t satkey = 0u;
             if (have) {
-                o = ld3(p.raypos + r * 3);
-                d = ld3(p.raydir + r * 3);
-                tmin = p.tminmax[r * 2];
-                const float4 g4 = reinterpret_cast<const float4 *>(p.grad_rayrgba)[r];
+                o = ld3(at_bytes<float>(raypos_n, r * 12u));
+                d = ld3(at_bytes<float>(raydir_n, r * 12u));
+                tmin = *at_bytes<float>(tminmax_n, r * 8u);
+                const float4 g4 = *at_bytes<float4>(grad_n, r * 16u);
                 dL3 = mk3(g4.x, g4.y, g4.z);
                 dLw = g4.w;
-                rsat = ld3(p.raysat_in + r * 3);
-                const uint4 aux = reinterpret_cast<const uint4 *>(p.rayaux)[r];
+                rsat = ld3(at_bytes<float>(raysat_n, r * 12u));
+                const uint4 aux = *at_bytes<uint4>(aux_n, r * 16u);
                 satkey = aux.x;
                 wbefore = __uint_as_float(aux.y);
                 tend = __uint_as_float(aux.w);
@@ -1418,9 +1432,17 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         }
     }
     __syncthreads();
+    // The output addresses below depend only on (n, k, tid); left alone, the compiler computes them at kernel entry
+    // (they also serve the early-exit zero-fill) and carries 9 pointer pairs through the whole march -- which is what
+    // pushed this kernel over its 168-VGPR budget into scratch.  Re-deriving them from a laundered copy of pk keeps
+    // them out of the hot loop's live set.
+    size_t pkl = pk;
+    int tl = tid;
+    asm volatile("; late address base" : "+s"(pkl), "+v"(tl));
+    float4 *gT4l = reinterpret_cast<float4 *>(p.grad_tplate) + pkl * (size_t)V;
     {  // the slab gradient, written exactly once: (hi * 2^16 + lo) / scale
         const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
-        for (int v = tid; v < V; v += kPrimBlock) {
+        for (int v = tl; v < V; v += kPrimBlock) {
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
@@ -1428,22 +1450,22 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             g.y = s_gf[Vp + gv] + ((float)s_hi[Vp + gv] * 65536.f + (float)s_lo[Vp + gv]) * i_rgb;
             g.z = s_gf[2 * Vp + gv] + ((float)s_hi[2 * Vp + gv] * 65536.f + (float)s_lo[2 * Vp + gv]) * i_rgb;
             g.w = s_gf[3 * Vp + gv] + ((float)s_hi[3 * Vp + gv] * 65536.f + (float)s_lo[3 * Vp + gv]) * i_a;
-            gT4[v] = g;
+            gT4l[v] = g;
         }
     }
-    if (tid < 12) s_red[48 + tid] = s_red[tid] + s_red[12 + tid] + s_red[24 + tid] + s_red[36 + tid];
+    if (tl < 12) s_red[48 + tl] = s_red[tl] + s_red[12 + tl] + s_red[24 + tl] + s_red[36 + tl];
     __syncthreads();
-    if (tid < 15) {
-        const float *Rg = p.primrot + pk * 9, *sg = p.primscale + pk * 3;
+    if (tl < 15) {
+        const float *Rg = p.primrot + pkl * 9, *sg = p.primscale + pkl * 3;
         const float *A = s_red + 48, *C = s_red + 51;  // A[j] = sum gy_j ; C[i*3+j] = sum xmt_i * gy_j
-        if (tid < 9) {
-            p.grad_primrot[pk * 9 + tid] = sg[tid % 3] * C[tid];  // xmt_i * (gy_j * s_j)
-        } else if (tid < 12) {
-            const int j = tid - 9;  // sum_i R[i][j] * C[i][j] = sum rxmt_j * gy_j
-            p.grad_primscale[pk * 3 + j] = Rg[j] * C[j] + Rg[3 + j] * C[3 + j] + Rg[6 + j] * C[6 + j];
+        if (tl < 9) {
+            p.grad_primrot[pkl * 9 + tl] = sg[tl % 3] * C[tl];  // xmt_i * (gy_j * s_j)
+        } else if (tl < 12) {
+            const int j = tl - 9;  // sum_i R[i][j] * C[i][j] = sum rxmt_j * gy_j
+            p.grad_primscale[pkl * 3 + j] = Rg[j] * C[j] + Rg[3 + j] * C[3 + j] + Rg[6 + j] * C[6 + j];
         } else {
-            const int ii = tid - 12;
-            p.grad_primpos[pk * 3 + ii] =
+            const int ii = tl - 12;
+            p.grad_primpos[pkl * 3 + ii] =
                 -(Rg[ii * 3 + 0] * sg[0] * A[0] + Rg[ii * 3 + 1] * sg[1] * A[1] + Rg[ii * 3 + 2] * sg[2] * A[2]);
         }
     }

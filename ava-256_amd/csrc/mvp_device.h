@@ -27,6 +27,13 @@ __device__ __forceinline__ void st3(float *p, f3 v) {
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// base + 32-bit BYTE offset: lets the backend address with a scalar base and a zero-extended vector offset
+// (global_load ... v_off, s[base:base+1]) instead of carrying a 64-bit address in two VGPRs per stream
+template <class T>
+__device__ __forceinline__ const T *at_bytes(const void *base, uint32_t byte_off) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 // ---- wave64 cross-lane helpers ------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
