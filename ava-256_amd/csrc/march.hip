@@ -1008,8 +1008,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // Slab-gradient accumulation.  Measured on MI355X (tools/ubench/lds_atomic.hip): ds_add_f32 retires ~3 cycles
 // per ACTIVE LANE (193 cycles per wave64 instruction, any address pattern) while ds_add_u32 takes 4.8 cycles per
 // wave instruction when conflict-free.  The 32 contributions of a sample are therefore accumulated in fixed
-// point with integer LDS atomics: t = int(value * 2^e * 2^16); hi += t >> 16; lo += t & 0xffff (two int32
-// accumulators per slab float).  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed
+// point with integer LDS atomics: t = int(value * 2^e * 2^16); hi += t >> 16; lo += t, wrapping (two int32
+// accumulators per slab float; fix_value() below puts them back together).  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed
 // bound B of any single contribution (|value * 2^e| < 2^14), so sums of up to 65536 contributions cannot
 // overflow; the resolution is 2^-30 * B.  Sums are exact integers => the slab gradient is bit-reproducible run
 // to run (the fp32-atomic formulation is not).  The exact number of samples each round can add is counted while
@@ -1020,6 +1020,9 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // ~5 x 5 in two box axes and straddles two layers of the third; with the natural stride (a multiple of 32 banks)
 // the two layers would collide bank for bank.
 // =================================================================================================
+#ifndef MVP_EXP
+#define MVP_EXP 0  // timing experiments only (tools/exp_variants.sh); anything but 0 computes wrong gradients
+#endif
 constexpr int kPrimBlock = 256;
 constexpr int kFixHiBits = 14;
 constexpr uint32_t kFixMaxSamples = 65536u;
@@ -1046,6 +1049,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float4 *__restrict__ 
 __device__ __forceinline__ float fix_scale(float B) {
     const int e = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;  // floor(log2 B)
     return __uint_as_float((uint32_t)(127 + kFixHiBits - 1 - e) << 23);
+}
+
+// Value of one fixed-point accumulator pair.  `hi` holds sum(t >> 16); `lo` holds sum(t) modulo 2^32 (the full word is
+// added, no masking in the hot loop).  With r = sum(t & 0xffff) in [0, 2^16 * n), n <= 65536 samples between drains,
+// sum(t) = hi * 2^16 + r and r = (lo - (hi << 16)) mod 2^32 exactly.
+__device__ __forceinline__ float fix_value(int hi, uint32_t lo) {
+    const uint32_t r = lo - ((uint32_t)hi << 16);
+    return (float)hi * 65536.f + (float)r;
 }
 
 template <bool FADE8>
@@ -1262,7 +1273,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             asm volatile("; drain addresses are made here" : "+v"(td));
             for (int v = td; v < 4 * Vp; v += kPrimBlock) {
                 const float inv = v < 3 * Vp ? i_rgb : i_a;
-                s_gf[v] += ((float)s_hi[v] * 65536.f + (float)s_lo[v]) * inv;
+                s_gf[v] += fix_value(s_hi[v], s_lo[v]) * inv;
                 s_hi[v] = 0;
                 s_lo[v] = 0u;
             }
@@ -1303,6 +1314,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
             const int nsteps = uni(wave_max(len));
             float ra0 = 0.f, ra1 = 0.f, ra2 = 0.f, rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
+#if MVP_EXP == 2
+            int exp_sink = 0;
+#endif
             for (int st = 0; st < nsteps; ++st) {
                 const int s = slo + st;
                 const float t = fmaf((float)s, dt, tmin);
@@ -1382,15 +1396,27 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
                     {
                         const float qx = dLs.x * s_rgb, qy = dLs.y * s_rgb, qz = dLs.z * s_rgb, qw = dLs.w * s_a;  // exact
+#if MVP_EXP == 1
+                        const int gb = (lane & 31) + 32 * (st % 14);
+#else
                         const int gb = z0 * gD + y0 * gH + x0;
+#endif
                         int *Hp = s_hi + gb;
                         uint32_t *Lp = s_lo + gb;
+#if MVP_EXP == 2
+#define MVP_FIX1(OFF_, VAL_)                                        \
+    {                                                               \
+        const int t_ = (int)(VAL_);                                 \
+        exp_sink ^= (t_ >> 16) + (int)(OFF_);                       \
+    }
+#else
 #define MVP_FIX1(OFF_, VAL_)                                        \
     {                                                               \
         const int t_ = (int)(VAL_);                                 \
         atomicAdd(Hp + (OFF_), t_ >> 16);                           \
-        atomicAdd(Lp + (OFF_), (uint32_t)t_ & 0xffffu);             \
+        atomicAdd(Lp + (OFF_), (uint32_t)t_);                       \
     }
+#endif
 #define MVP_LSCATTER(OFF_, WGT_)               \
     MVP_FIX1((OFF_), (WGT_) * qx)              \
     MVP_FIX1((OFF_) + Vp, (WGT_) * qy)         \
@@ -1407,6 +1433,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
 #undef MVP_LSCATTER
 #undef MVP_FIX1
                     }
+#if MVP_EXP == 2
+                    if (exp_sink == 0x12345678) s_hi[gD] = exp_sink;
+#endif
                     // xmt = (o - pos) + d * t is affine in t along this ray: keep sum(gy) and sum(t * gy) only
                     ra0 += gy.x, ra1 += gy.y, ra2 += gy.z;
                     rb0 = fmaf(t, gy.x, rb0), rb1 = fmaf(t, gy.y, rb1), rb2 = fmaf(t, gy.z, rb2);
@@ -1446,10 +1475,10 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
-            g.x = s_gf[gv] + ((float)s_hi[gv] * 65536.f + (float)s_lo[gv]) * i_rgb;
-            g.y = s_gf[Vp + gv] + ((float)s_hi[Vp + gv] * 65536.f + (float)s_lo[Vp + gv]) * i_rgb;
-            g.z = s_gf[2 * Vp + gv] + ((float)s_hi[2 * Vp + gv] * 65536.f + (float)s_lo[2 * Vp + gv]) * i_rgb;
-            g.w = s_gf[3 * Vp + gv] + ((float)s_hi[3 * Vp + gv] * 65536.f + (float)s_lo[3 * Vp + gv]) * i_a;
+            g.x = s_gf[gv] + fix_value(s_hi[gv], s_lo[gv]) * i_rgb;
+            g.y = s_gf[Vp + gv] + fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
+            g.z = s_gf[2 * Vp + gv] + fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
+            g.w = s_gf[3 * Vp + gv] + fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
             gT4l[v] = g;
         }
     }
