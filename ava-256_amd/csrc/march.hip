@@ -1051,6 +1051,8 @@ __device__ __forceinline__ float fix_scale(float B) {
     return __uint_as_float((uint32_t)(127 + kFixHiBits - 1 - e) << 23);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
+
 // Value of one fixed-point accumulator pair.  `hi` holds sum(t >> 16); `lo` holds sum(t) modulo 2^32 (the full word is
 // added, no masking in the hot loop).  With r = sum(t & 0xffff) in [0, 2^16 * n), n <= 65536 samples between drains,
 // sum(t) = hi * 2^16 + r and r = (lo - (hi << 16)) mod 2^32 exactly.
@@ -1059,12 +1061,15 @@ __device__ __forceinline__ float fix_value(int hi, uint32_t lo) {
     return (float)hi * 65536.f + (float)r;
 }
 
-template <bool FADE8>
+// TS > 0: the slab is TS^3 (compile-time strides: the 64 atomics and 8 reads of a sample share ONE address register and
+// use immediate offsets); TS == 0: any slab size, strides in registers.
+template <bool FADE8, int TS>
 __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchParams p) {
+    const int TD = TS ? TS : p.TD, TH = TS ? TS : p.TH, TW = TS ? TS : p.TW;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
-    const int V = p.TD * p.TH * p.TW;
-    const int gH = p.TW, gD = p.TH * p.TW + 4;  // gradient-array strides (words); x stride 1
-    const int Vp = p.TD * gD;
+    const int V = TD * TH * TW;
+    const int gH = TW, gD = TH * TW + 4;  // gradient-array strides (words); x stride 1
+    const int Vp = TD * gD;
     float4 *s_T = smem4;
     int *s_hi = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar
     uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_hi + 4 * Vp);
@@ -1155,8 +1160,8 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     const float *raypos_n = p.raypos + img * 3, *raydir_n = p.raydir + img * 3, *tminmax_n = p.tminmax + img * 2;
     const float *grad_n = p.grad_rayrgba + img * 4, *raysat_n = p.raysat_in + img * 3;
     const uint32_t *aux_n = p.rayaux + img * 4;
-    const int sW = 1, sH = p.TW, sD = p.TH * p.TW;  // voxel strides of the template slab
-    const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
+    const int sW = 1, sH = TW, sD = TH * TW;  // voxel strides of the template slab
+    const float mx = 0.5f * (float)(TW - 1), my = 0.5f * (float)(TH - 1), mz = 0.5f * (float)(TD - 1);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
@@ -1344,11 +1349,11 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                                    fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
                                    fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
                     }
-                    const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
-                    const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
-                    const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
-                    const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
-                              z0 = min((int)floorf(iz), p.TD - 2);
+                    const float ix = (y.x + 1.f) * 0.5f * (float)(TW - 1);
+                    const float iy = (y.y + 1.f) * 0.5f * (float)(TH - 1);
+                    const float iz = (y.z + 1.f) * 0.5f * (float)(TD - 1);
+                    const int x0 = min((int)floorf(ix), TW - 2), y0 = min((int)floorf(iy), TH - 2),
+                              z0 = min((int)floorf(iz), TD - 2);
                     const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
                     const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
                     const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
@@ -1395,7 +1400,8 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                                   wx1 * wy1 * (d111 - d011));
                     // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
                     {
-                        const float qx = dLs.x * s_rgb, qy = dLs.y * s_rgb, qz = dLs.z * s_rgb, qw = dLs.w * s_a;  // exact
+                        // scaled by powers of two (exact); pairs, so that weight x pair is one packed multiply
+                        const v2f qxy = {dLs.x * s_rgb, dLs.y * s_rgb}, qzw = {dLs.z * s_rgb, dLs.w * s_a};
 #if MVP_EXP == 1
                         const int gb = (lane & 31) + 32 * (st % 14);
 #else
@@ -1417,11 +1423,14 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         atomicAdd(Lp + (OFF_), (uint32_t)t_);                       \
     }
 #endif
-#define MVP_LSCATTER(OFF_, WGT_)               \
-    MVP_FIX1((OFF_), (WGT_) * qx)              \
-    MVP_FIX1((OFF_) + Vp, (WGT_) * qy)         \
-    MVP_FIX1((OFF_) + 2 * Vp, (WGT_) * qz)     \
-    MVP_FIX1((OFF_) + 3 * Vp, (WGT_) * qw)
+#define MVP_LSCATTER(OFF_, WGT_)                                    \
+    {                                                               \
+        const v2f a_ = qxy * (WGT_), b_ = qzw * (WGT_);             \
+        MVP_FIX1((OFF_), a_.x)                                      \
+        MVP_FIX1((OFF_) + Vp, a_.y)                                 \
+        MVP_FIX1((OFF_) + 2 * Vp, b_.x)                             \
+        MVP_FIX1((OFF_) + 3 * Vp, b_.y)                             \
+    }
                         MVP_LSCATTER(0, w000)
                         MVP_LSCATTER(1, w001)
                         MVP_LSCATTER(gH, w010)
@@ -1650,10 +1659,15 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         const dim3 grid((unsigned)pb), block(kPrimBlock);
-        if (fade8)
-            hipLaunchKernelGGL((bwd_prim_kernel<true>), grid, block, lds, st, p);
+        const bool cube8 = TD == 8 && TH == 8 && TW == 8;  // the reference's slab size (and BASELINE's)
+        if (fade8 && cube8)
+            hipLaunchKernelGGL((bwd_prim_kernel<true, 8>), grid, block, lds, st, p);
+        else if (fade8)
+            hipLaunchKernelGGL((bwd_prim_kernel<true, 0>), grid, block, lds, st, p);
+        else if (cube8)
+            hipLaunchKernelGGL((bwd_prim_kernel<false, 8>), grid, block, lds, st, p);
         else
-            hipLaunchKernelGGL((bwd_prim_kernel<false>), grid, block, lds, st, p);
+            hipLaunchKernelGGL((bwd_prim_kernel<false, 0>), grid, block, lds, st, p);
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         p.fallback_all = 0;
