@@ -1358,21 +1358,29 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
                     const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
                     const int vb = z0 * sD + y0 * sH + x0 * sW;
-                    const float4 c000 = s_T[vb], c001 = s_T[vb + sW], c010 = s_T[vb + sH], c011 = s_T[vb + sH + sW];
-                    const float4 c100 = s_T[vb + sD], c101 = s_T[vb + sD + sW], c110 = s_T[vb + sD + sH],
-                                 c111 = s_T[vb + sD + sH + sW];
-                    const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
-                                w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
-                                w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+                    // Corner values are kept as the (x,y) / (z,w) register pairs the 16-byte LDS reads deliver, so that
+                    // interpolation and the 8 dot products below are packed-fp32 instructions on natural pairs.
+#define MVP_LOADC(NAME_, IDX_)              \
+    const float4 NAME_##q = s_T[IDX_];      \
+    const v2f NAME_##l = {NAME_##q.x, NAME_##q.y}, NAME_##h = {NAME_##q.z, NAME_##q.w};
+                    MVP_LOADC(c000, vb)
+                    MVP_LOADC(c001, vb + sW)
+                    MVP_LOADC(c010, vb + sH)
+                    MVP_LOADC(c011, vb + sH + sW)
+                    MVP_LOADC(c100, vb + sD)
+                    MVP_LOADC(c101, vb + sD + sW)
+                    MVP_LOADC(c110, vb + sD + sH)
+                    MVP_LOADC(c111, vb + sD + sH + sW)
+#undef MVP_LOADC
+                    const float wyz00 = wy0 * wz0, wyz10 = wy1 * wz0, wyz01 = wy0 * wz1, wyz11 = wy1 * wz1;
+                    const float w000 = wx0 * wyz00, w001 = wx1 * wyz00, w010 = wx0 * wyz10, w011 = wx1 * wyz10,
+                                w100 = wx0 * wyz01, w101 = wx1 * wyz01, w110 = wx0 * wyz11, w111 = wx1 * wyz11;
+                    const v2f vl = c000l * w000 + c001l * w001 + c010l * w010 + c011l * w011 + c100l * w100 +
+                                   c101l * w101 + c110l * w110 + c111l * w111;
+                    const v2f vh = c000h * w000 + c001h * w001 + c010h * w010 + c011h * w011 + c100h * w100 +
+                                   c101h * w101 + c110h * w110 + c111h * w111;
                     float4 v;
-                    v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 +
-                          c101.x * w101 + c110.x * w110 + c111.x * w111;
-                    v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 +
-                          c101.y * w101 + c110.y * w110 + c111.y * w111;
-                    v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 +
-                          c101.z * w101 + c110.z * w110 + c111.z * w111;
-                    v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 +
-                          c101.w * w101 + c110.w * w110 + c111.w * w111;
+                    v.x = vl.x, v.y = vl.y, v.z = vh.x, v.w = vh.y;
                     const float alpha = v.w * fade;
                     const bool issat = key == satkey;
                     const float weight = issat ? (1.f - wbefore) : alpha * dt;
@@ -1387,13 +1395,24 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
                     f3 gy = ypow * gf;
                     dLs.w *= fade;
-#define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
-                    const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
-                                d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
-                                d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
+                    const v2f dl = {dLs.x, dLs.y}, dh = {dLs.z, dLs.w};
+#define MVP_DOT4(NAME_, C_)                                 \
+    float NAME_;                                            \
+    {                                                       \
+        const v2f p_ = C_##l * dl + C_##h * dh;             \
+        NAME_ = p_.x + p_.y;                                \
+    }
+                    MVP_DOT4(d000, c000)
+                    MVP_DOT4(d001, c001)
+                    MVP_DOT4(d010, c010)
+                    MVP_DOT4(d011, c011)
+                    MVP_DOT4(d100, c100)
+                    MVP_DOT4(d101, c101)
+                    MVP_DOT4(d110, c110)
+                    MVP_DOT4(d111, c111)
 #undef MVP_DOT4
-                    gy.x += mx * (wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) + wy0 * wz1 * (d101 - d100) +
-                                  wy1 * wz1 * (d111 - d110));
+                    gy.x += mx * (wyz00 * (d001 - d000) + wyz10 * (d011 - d010) + wyz01 * (d101 - d100) +
+                                  wyz11 * (d111 - d110));
                     gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
                                   wx1 * wz1 * (d111 - d101));
                     gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
