@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
 //   LDS: [V] float4 template slab | [4][Vp] int32 gradient "hi" | [4][Vp] uint32 gradient "lo" |
-//        [4][Vp] float drain target | ray queue (512 x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + 4, see below).
+//        [4][Vp] float drain target | ray queue (kQueueCap x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + 4, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
 //             COMPACTED into the LDS queue (ballot + popcount prefix inside the wave, one LDS integer atomic per
@@ -1026,8 +1026,9 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 constexpr int kPrimBlock = 256;
 constexpr int kFixHiBits = 14;
 constexpr uint32_t kFixMaxSamples = 65536u;
-constexpr int kQueueCap = 512;      // rays per round: 8 entries x 64 lanes
-constexpr int kEntriesPerRound = 8;  // two per wave
+constexpr int kEntriesPerWave = 4;   // list entries (packets) each wave examines per round
+constexpr int kEntriesPerRound = 4 * kEntriesPerWave;  // typical lists (~10 entries at C2) finish in ONE round
+constexpr int kQueueCap = kEntriesPerRound * 64;       // rays per round
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
 
 // G = max |grad_rayrgba| -> out[0] (float bits; non-negative floats order like uints).  max |raysat| (out[1]) is
@@ -1178,17 +1179,17 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                        "+s"(q.r1.x), "+s"(q.r1.y), "+s"(q.r1.z), "+s"(q.r2.x), "+s"(q.r2.y), "+s"(q.r2.z),
                        "+s"(q.scale.x), "+s"(q.scale.y), "+s"(q.scale.z));
         // ---------------- phase 1: which rays of these packets cross the box, and over which steps ----------------
-        // Each wave owns up to two entries of the round; a live ray takes a ticket in the bucket of its step count
+        // Each wave owns up to kEntriesPerWave entries of the round; a live ray takes a ticket in the bucket of its step count
         // (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the
         // 64 rays a wave marches together have (nearly) the same number of steps.
         const uint32_t eend = min(cnt, ebase + (uint32_t)kEntriesPerRound);
-        uint4 item[2];
-        uint32_t ticket[2];
-        bool live2[2];
+        uint4 item[kEntriesPerWave];
+        uint32_t ticket[kEntriesPerWave];
+        bool live2[kEntriesPerWave];
         bool toolong = false;
         uint32_t mylen = 0u;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kEntriesPerWave; ++u) {
             const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
             live2[u] = false;
             ticket[u] = 0u;
@@ -1222,7 +1223,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     }
                 }
                 if (slo <= shi) {
-                    // at most 127 steps per queued item, so that one round adds <= 512 * 127 < 65536 samples; a box
+                    // at most 127 steps per queued item (the len field and the buckets assume short crossings); a box
                     // that is deeper than that along some ray is handed to the ray-centric kernel (flagged below)
                     const int len = shi - slo + 1;
                     if (len > 127) toolong = true;
@@ -1239,7 +1240,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             if (lane == 0 && wl > 0.f) atomicAdd(s_qn + 1, (uint32_t)wl);
         }
         __syncthreads();
-        if (s_qn[2] != 0u) {  // a ray crosses this box over more than 127 steps: not this kernel's case
+        // a ray crosses this box over more than 127 steps, or the round alone would add more samples than the integer
+        // accumulators can take between two drains: not this kernel's case
+        if (s_qn[2] != 0u || s_qn[1] > kFixMaxSamples) {
             if (tid == 0) {
                 p.pl_count[pk] = 0xffffffffu;
                 atomicOr(tail, kFlagListOverflow);
@@ -1256,18 +1259,21 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             if (tz < 3) p.grad_primpos[pkz * 3 + tz] = 0.f;
             return;
         }
-        if (tid == 0) {  // exclusive prefix over the buckets, longest rays first
-            uint32_t acc = 0u;
-            for (int bkt = kLenBuckets - 1; bkt >= 0; --bkt) {
-                const uint32_t c = s_bucket[bkt];
-                s_bucket[bkt] = acc;
-                acc += c;
+        if (wave == 0) {  // exclusive prefix over the buckets, longest rays first (lane j <-> bucket kLenBuckets-1-j)
+            const bool mine = lane < kLenBuckets;
+            const uint32_t c = mine ? s_bucket[kLenBuckets - 1 - lane] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < kLenBuckets; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= d) incl += up;
             }
-            *s_qn = acc;
+            if (mine) s_bucket[kLenBuckets - 1 - lane] = incl - c;
+            if (lane == kLenBuckets - 1) *s_qn = incl;
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < kEntriesPerWave; ++u)
             if (live2[u]) s_q[s_bucket[min((int)(item[u].y >> 16), kLenBuckets) - 1] + ticket[u]] = item[u];
         __syncthreads();
         // ---------------- drain the integer accumulators before they could overflow ----------------
@@ -1285,7 +1291,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             pending = 0u;
             __syncthreads();
         }
-        pending += round_samples;  // a single round holds <= 512 rays x 65535 steps; see the guard below
+        pending += round_samples;  // <= kFixMaxSamples by the guard above
         // ---------------- phase 2: the queued rays, split evenly over the 4 waves ----------------
         const int nq = (int)*s_qn;
         const int per = min(kWave, (nq + 3) >> 2);
@@ -1653,7 +1659,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
     const size_t Vp = (size_t)TD * ((size_t)TH * TW + 4);
     // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
-    const size_t lds = V * 16 + Vp * 48 + 512 * 16 + 64 * sizeof(float) + 16 + 32 * 4;
+    const size_t lds = V * 16 + Vp * 48 + (size_t)kQueueCap * 16 + 64 * sizeof(float) + 16 + kLenBuckets * 4;
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
     const bool prim_path = !norays && have_lists && lds <= 64 * 1024 && warp == nullptr;
     const bool fade8 = fadeexp == 8.0f;
