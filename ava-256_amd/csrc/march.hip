@@ -152,6 +152,8 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d)
     return a;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
+
 // One ray packet (8x8 pixels, one wave).  s_a: frontier ping, later packed step ranges (lo | hi << 16);
 // s_b: frontier pong / candidate list / final list (k | slot << 24); s_rec: SRT records of the first 64 candidates.
 // BWD instantiation = ray-centric fallback backward; emit_all: it owns every primitive (else only overflowed ones).
@@ -198,6 +200,47 @@ __device__ __forceinline__ float4 sample_slab(const float *__restrict__ Tk, f3 y
     v.w = (c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 + c101.w * w101 +
            c110.w * w110 + c111.w * w111) * fade;
     return v;
+}
+
+// The same for a TS^3 slab with compile-time strides.  Timg = the image's template block (wave-uniform, SGPR pair),
+// kbyte = byte offset of this lane's slab inside it (< 2^32, checked by the host): every gather is
+// "scalar base + 32-bit lane offset + immediate", no 64-bit address arithmetic in the sweep.
+template <bool FADE8, int TS>
+__device__ __forceinline__ float4 sample_slab_c(const float *__restrict__ Timg, uint32_t kbyte, f3 y, float fadescale,
+                                                float fadeexp) {
+    float fade;
+    if (FADE8) {
+        const f3 y2 = y * y, y4 = y2 * y2;
+        fade = fast_exp(-fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+    } else {
+        fade = fast_exp(-fadescale * (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp) +
+                                      fast_pow(fabsf(y.z), fadeexp)));
+    }
+    constexpr float m = (float)(TS - 1);
+    const float ix = (y.x + 1.f) * 0.5f * m, iy = (y.y + 1.f) * 0.5f * m, iz = (y.z + 1.f) * 0.5f * m;
+    const int x0 = min((int)floorf(ix), TS - 2), y0 = min((int)floorf(iy), TS - 2), z0 = min((int)floorf(iz), TS - 2);
+    const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
+    const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+    const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+    constexpr int bW = 16, bH = TS * 16, bD = TS * TS * 16;  // byte strides
+    const uint32_t off = kbyte + (uint32_t)(z0 * bD + y0 * bH + x0 * bW);
+    const char *pc = reinterpret_cast<const char *>(Timg) + (size_t)off;
+#define MVP_C(O_) (*reinterpret_cast<const float4 *>(pc + (O_)))
+    const float4 c000 = MVP_C(0), c001 = MVP_C(bW), c010 = MVP_C(bH), c011 = MVP_C(bH + bW);
+    const float4 c100 = MVP_C(bD), c101 = MVP_C(bD + bW), c110 = MVP_C(bD + bH), c111 = MVP_C(bD + bH + bW);
+#undef MVP_C
+    const float wyz00 = wy0 * wz0, wyz10 = wy1 * wz0, wyz01 = wy0 * wz1, wyz11 = wy1 * wz1;
+    const float w000 = wx0 * wyz00, w001 = wx1 * wyz00, w010 = wx0 * wyz10, w011 = wx1 * wyz10, w100 = wx0 * wyz01,
+                w101 = wx1 * wyz01, w110 = wx0 * wyz11, w111 = wx1 * wyz11;
+#define MVP_L(C_) v2f{(C_).x, (C_).y}
+#define MVP_H(C_) v2f{(C_).z, (C_).w}
+    const v2f vl = MVP_L(c000) * w000 + MVP_L(c001) * w001 + MVP_L(c010) * w010 + MVP_L(c011) * w011 +
+                   MVP_L(c100) * w100 + MVP_L(c101) * w101 + MVP_L(c110) * w110 + MVP_L(c111) * w111;
+    const v2f vh = MVP_H(c000) * w000 + MVP_H(c001) * w001 + MVP_H(c010) * w010 + MVP_H(c011) * w011 +
+                   MVP_H(c100) * w100 + MVP_H(c101) * w101 + MVP_H(c110) * w110 + MVP_H(c111) * w111;
+#undef MVP_L
+#undef MVP_H
+    return make_float4(vl.x, vl.y, vh.x, vh.y * fade);
 }
 
 // ---- warp-field path (algo 1: PrimSamplerTW<true>, primsampler.h:53-58,82-88) -------------------------------------
@@ -288,7 +331,7 @@ __device__ __forceinline__ bool lane_step_range(float tn, float tf, float tmin, 
     return lo <= hi;
 }
 
-template <bool BWD, bool FADE8, bool WARP>
+template <bool BWD, bool FADE8, bool WARP, int TS>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
                                              const bool emit_all) {
     const int lane = lane_id();
@@ -644,7 +687,11 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             const int bit = __ffsll((long long)mine) - 1;
                             mine &= mine - 1ull;
                             const int ent = s_b[ch * kWave + bit];
-                            const int k = ent & 0xffffff, slot = (ent >> 24) & 0xff;
+                            int k = ent & 0xffffff;
+                            const int slot = (ent >> 24) & 0xff;
+                            // Opaque on purpose: with the TS > 0 sampler below, hipcc (ROCm 7.2) dropped this mask and fed
+                            // the raw entry (slot bits included) to the 64-bit address of the record loads -> wild reads.
+                            asm volatile("; k = entry & 0xffffff" : "+v"(k));
                             const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
                             const f3 y = rot_rows(q, x - q.pos) * q.scale;
                             float4 v;
@@ -654,7 +701,12 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                                 v = tplate_lookup_general(T + (size_t)k * V4, y1, p.TD, p.TH, p.TW);
                                 v.w *= fade_of<FADE8>(y, p.fadescale, p.fadeexp);
                             } else {
-                                v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale, p.fadeexp);
+                                if constexpr (TS > 0)
+                                    v = sample_slab_c<FADE8, TS>(T, (uint32_t)k * (uint32_t)(TS * TS * TS * 16), y,
+                                                                 p.fadescale, p.fadeexp);
+                                else
+                                    v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale,
+                                                           p.fadeexp);
                             }
                             // ---- primaccum.h:63-79 ----
                             const float newalpha = rgba.w + v.w * dt;
@@ -967,7 +1019,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
 }
 
-template <bool BWD, bool FADE8, bool WARP>
+// TS > 0 (forward, no warp field): TS^3 slabs with compile-time strides, see sample_slab_c
+template <bool BWD, bool FADE8, bool WARP, int TS = 0>
 __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     __shared__ int s_a[kMaxList];
     __shared__ int s_b[kMaxList];
@@ -980,11 +1033,11 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
             emit_all = (flags & kFlagGlobal) != 0u;
         }
         for (int b = blockIdx.x; b < p.total_packets; b += gridDim.x) {
-            march_packet<BWD, FADE8, WARP>(p, b, s_a, s_b, s_rec, emit_all);
+            march_packet<BWD, FADE8, WARP, TS>(p, b, s_a, s_b, s_rec, emit_all);
             __syncthreads();
         }
     } else {
-        march_packet<BWD, FADE8, WARP>(p, blockIdx.x, s_a, s_b, s_rec, true);
+        march_packet<BWD, FADE8, WARP, TS>(p, blockIdx.x, s_a, s_b, s_rec, true);
     }
 }
 
@@ -1051,8 +1104,6 @@ __device__ __forceinline__ float fix_scale(float B) {
     const int e = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;  // floor(log2 B)
     return __uint_as_float((uint32_t)(127 + kFixHiBits - 1 - e) << 23);
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
 
 // Value of one fixed-point accumulator pair.  `hi` holds sum(t >> 16); `lo` holds sum(t) modulo 2^32 (the full word is
 // added, no masking in the hot loop).  With r = sum(t & 0xffff) in [0, 2^16 * n), n <= 65536 samples between drains,
@@ -1616,8 +1667,14 @@ extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos
         else
             hipLaunchKernelGGL((march_kernel<false, false, true>), grid, block, 0, st, p);
     } else {
-        if (fade8)
+        // the reference's slab size (and BASELINE's) gets compile-time strides and 32-bit slab offsets
+        const bool cube8 = TD == 8 && TH == 8 && TW == 8 && (unsigned long long)K * 8192ull < (1ull << 32);
+        if (fade8 && cube8)
+            hipLaunchKernelGGL((march_kernel<false, true, false, 8>), grid, block, 0, st, p);
+        else if (fade8)
             hipLaunchKernelGGL((march_kernel<false, true, false>), grid, block, 0, st, p);
+        else if (cube8)
+            hipLaunchKernelGGL((march_kernel<false, false, false, 8>), grid, block, 0, st, p);
         else
             hipLaunchKernelGGL((march_kernel<false, false, false>), grid, block, 0, st, p);
     }
