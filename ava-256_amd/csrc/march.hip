@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
 //   LDS: [V] float4 template slab | [4][Vp] int32 gradient "hi" | [4][Vp] uint32 gradient "lo" |
-//        [4][Vp] float drain target | ray queue (kQueueCap x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + 4, see below).
+//        [4][Vp] float drain target | ray queue (kQueueCap x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
 //             COMPACTED into the LDS queue (ballot + popcount prefix inside the wave, one LDS integer atomic per
@@ -1069,15 +1069,21 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // the rays are queued; before the running total could pass 65536 the integer sums are drained into a float array
 // in LDS (plain adds by the owning threads) and restart from zero, so any number of samples per primitive is fine.
 // Primitives with a non-finite bound are handed to the ray-centric kernel through the forward's overflow flag.
-// The gradient arrays use a z stride of TH*TW + 4 words: the rays of a batch sit on a sheet of cells that is
-// ~5 x 5 in two box axes and straddles two layers of the third; with the natural stride (a multiple of 32 banks)
-// the two layers would collide bank for bank.
+// The gradient arrays use a z stride of TH*TW + kGradPadZ words.  With the natural stride (a multiple of the 32 banks)
+// two layers of cells collide bank for bank.  Measured at C2 (tools/exp4_stats.py): a 32-lane group has ~23 active
+// lanes, at most ~2.05 of them on one address, and the busiest bank serves 3.25 lanes with pad 4 but 2.93 with pad 5
+// (other (y stride, z stride) pairs tried: 2.90-3.20; the lanes' cells are close to random, so ~2.9 is the floor for
+// a linear layout).
 // =================================================================================================
 #ifndef MVP_EXP
-#define MVP_EXP 0  // timing experiments only (tools/exp_variants.sh); anything but 0 computes wrong gradients
+// Timing experiments of the primitive-centric backward (tools/exp_variants.sh builds them, never the product library):
+//   1 = conflict-free scatter addresses, 2 = no scatter atomics (both compute WRONG gradients: time only),
+//   4 = count same-address / same-bank lanes per 32-lane group into diag (tools/exp4_stats.py).
+#define MVP_EXP 0
 #endif
 constexpr int kPrimBlock = 256;
 constexpr int kFixHiBits = 14;
+constexpr int kGradPadZ = 5;  // see the note on the gradient arrays above
 constexpr uint32_t kFixMaxSamples = 65536u;
 constexpr int kEntriesPerWave = 4;   // list entries (packets) each wave examines per round
 constexpr int kEntriesPerRound = 4 * kEntriesPerWave;  // typical lists (~10 entries at C2) finish in ONE round
@@ -1120,14 +1126,14 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     const int TD = TS ? TS : p.TD, TH = TS ? TS : p.TH, TW = TS ? TS : p.TW;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int V = TD * TH * TW;
-    const int gH = TW, gD = TH * TW + 4;  // gradient-array strides (words); x stride 1
+    const int gH = TW, gD = TH * TW + kGradPadZ;  // gradient-array strides (words); x stride 1
     const int Vp = TD * gD;
     float4 *s_T = smem4;
     int *s_hi = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar
     uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_hi + 4 * Vp);
     float *s_gf = reinterpret_cast<float *>(s_lo + 4 * Vp);  // [4][Vp] float: receives the integer sums whenever the
                                                              // per-slab sample count since the last drain nears 65536
-    uint4 *s_q = reinterpret_cast<uint4 *>(s_gf + 4 * Vp);  // Vp % 4 == 0 keeps this 16-byte aligned
+    uint4 *s_q = reinterpret_cast<uint4 *>(s_gf + 4 * Vp);  // 12*Vp words past a 16-byte aligned base
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
@@ -1217,6 +1223,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
+#if MVP_EXP == 4
+    uint32_t ex_groups = 0u, ex_addr = 0u, ex_lanes = 0u, ex_bank[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
+#endif
     if (tid == 0) s_qn[2] = 0u;
     uint32_t pending = 0u;  // samples accumulated into the integer arrays since the last drain (workgroup-uniform)
     for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
@@ -1390,6 +1399,41 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                 const bool inside = st < len && t < tend && key <= satkey && y.x > -1.f && y.x < 1.f && y.y > -1.f &&
                                     y.y < 1.f && y.z > -1.f && y.z < 1.f;
                 if (__ballot(inside) == 0ull) continue;
+#if MVP_EXP == 4
+                {   // per 32-lane group: max number of lanes on one address / on one bank (= LDS cycles of one atomic),
+                    // for the current layout and for candidate (y stride, z stride mod 32) pairs
+                    int code = -1;
+                    if (inside) {
+                        const float jx = (y.x + 1.f) * 0.5f * (float)(TW - 1), jy = (y.y + 1.f) * 0.5f * (float)(TH - 1),
+                                    jz = (y.z + 1.f) * 0.5f * (float)(TD - 1);
+                        code = min((int)floorf(jx), TW - 2) | (min((int)floorf(jy), TH - 2) << 4) |
+                               (min((int)floorf(jz), TD - 2) << 8);
+                    }
+                    constexpr int NH = 8;
+                    const int hy[NH] = {8, 8, 8, 8, 9, 9, 10, 12}, hz[NH] = {4, 5, 12, 20, 17, 5, 20, 3};
+                    int na = 0, nb[NH];
+                    for (int h = 0; h < NH; ++h) nb[h] = 0;
+                    const int cx = code & 15, cy = (code >> 4) & 15, cz = (code >> 8) & 15;
+                    for (int j = 0; j < 32; ++j) {
+                        const int o0 = __builtin_amdgcn_readlane(code, j), o1 = __builtin_amdgcn_readlane(code, j + 32);
+                        const int o = lane < 32 ? o0 : o1;
+                        if (code >= 0 && o >= 0) {
+                            na += (o == code) ? 1 : 0;
+                            const int ox = o & 15, oy = (o >> 4) & 15, oz = (o >> 8) & 15;
+#pragma unroll
+                            for (int h = 0; h < NH; ++h)
+                                nb[h] += (((ox - cx) + hy[h] * (oy - cy) + hz[h] * (oz - cz)) & 31) == 0 ? 1 : 0;
+                        }
+                    }
+                    const int a0 = uni(wave_max(lane < 32 ? na : 0)), a1 = uni(wave_max(lane < 32 ? 0 : na));
+                    ex_groups += (a0 > 0) + (a1 > 0);
+                    ex_addr += (uint32_t)(a0 + a1);
+                    ex_lanes += (uint32_t)__popcll(__ballot(inside));
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        ex_bank[h] += (uint32_t)(uni(wave_max(lane < 32 ? nb[h] : 0)) + uni(wave_max(lane < 32 ? 0 : nb[h])));
+                }
+#endif
                 if (inside) {
                     float fade;
                     f3 ypow;
@@ -1536,6 +1580,14 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         }
         __syncthreads();  // the queue is rewritten by the next round
     }
+#if MVP_EXP == 4
+    if (p.diag && lane == 0) {
+        atomicAdd(p.diag + 0, ex_groups);
+        atomicAdd(p.diag + 1, ex_addr);
+        atomicAdd(p.diag + 2, ex_lanes);
+        for (int h = 0; h < 8; ++h) atomicAdd(p.diag + 8 + h, ex_bank[h]);
+    }
+#endif
     // ---- pose gradients: 12 sums per lane -> wave -> workgroup (primtransf.h:155-179) ----
     {
         const float sums[12] = {wave_sum(a0),  wave_sum(a1),  wave_sum(a2),  wave_sum(c00), wave_sum(c01), wave_sum(c02),
@@ -1714,7 +1766,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     const size_t V = (size_t)TD * TH * TW;
     const bool norays = (long long)N * H * W == 0;
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
-    const size_t Vp = (size_t)TD * ((size_t)TH * TW + 4);
+    const size_t Vp = (size_t)TD * ((size_t)TH * TW + kGradPadZ);
     // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
     const size_t lds = V * 16 + Vp * 48 + (size_t)kQueueCap * 16 + 64 * sizeof(float) + 16 + kLenBuckets * 4;
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;

@@ -18,6 +18,7 @@ for r in rows:
 with open(sys.argv[2], "w") as f:
     f.write("kernel,dispatches,counter,sum,per_dispatch\n")
     for k in agg:
+        if "mvp" not in k: continue   # torch's own kernels are not evidence for anything here
         for c, v in agg[k].items():
             line = "%s,%d,%s,%.6g,%.6g" % (k, len(cnt[k]), c, v, v / max(1, len(cnt[k])))
             f.write(line + "\n")
