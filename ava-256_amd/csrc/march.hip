@@ -400,6 +400,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             const float2 *ap = reinterpret_cast<const float2 *>(A);  // root AABB, wave-uniform
             const float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
             if (!packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y)) ncur = 0;
+            if (p.debug_stage == 11) ncur = 0;
         }
         // Coarse pre-cull of the implicit level: its nodes are grouped 32 per ancestor 5 levels up (<= 32 ancestors,
         // one lane each); groups whose ancestor fails the packet test are skipped without touching their boxes.
@@ -413,7 +414,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 ok = packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
             }
             anc_pass = (unsigned)__ballot(ok);
-            if (anc_pass == 0u) ncur = 0;
+            if (anc_pass == 0u || p.debug_stage == 12) ncur = 0;
         }
         for (int dep = ds; ncur > 0; ++dep) {
             int nnext = 0;
@@ -447,6 +448,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             cur = nxt;
             nxt = t;
             ncur = nnext;
+            if (p.debug_stage == 13) ncur = 0;
             if (dep >= dmax) break;
         }
         ncand = ncur;  // entries of `cur` are ~node of tested leaves, in DFS (left-to-right) order
@@ -1004,11 +1006,17 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
 
     if (!BWD && p.pl_count != nullptr) {
-        // max |raysat| over the packet -> tail word [2] (the backward's fixed-point bound); |-1| = 1 when unsaturated
+        // max |raysat| over the packet -> tail word [2] (the backward's fixed-point bound).  |-1| = 1 when unsaturated:
+        // the host pre-sets the word to 1.0f, and only a packet that can raise it touches it.  (One same-address
+        // atomic per packet -- 327 680 of them at C2 -- serialised in L2 and cost 2.5 ms of a 9.4 ms kernel.)
         float m = inimg ? fmaxf(fabsf(raysat.x), fmaxf(fabsf(raysat.y), fabsf(raysat.z))) : 0.f;
         if (!(m == m)) m = INFINITY;
-        m = wave_max(m);
-        if (lane == 0) atomicMax(p.pl_count + (size_t)p.N * K + 2, __float_as_uint(m));
+        m = uni(wave_max(m));
+        if (m > 1.0f) {
+            uint32_t *word = p.pl_count + (size_t)p.N * K + 2;
+            const float cur = __uint_as_float(__atomic_load_n(word, __ATOMIC_RELAXED));  // stale is fine: monotone
+            if (m > cur && lane == 0) atomicMax(word, __float_as_uint(m));
+        }
     }
     if (!BWD && inimg) {
         reinterpret_cast<float4 *>(p.rayrgba)[r] = rgba;  // primaccum.h:51-56
@@ -1710,6 +1718,9 @@ extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos
             e = hipMemsetD32Async((hipDeviceptr_t)(primlist_count + (size_t)N * K), (int)kFlagGlobal, 1, st);
             if (e != hipSuccess) return (int)e;
         }
+        // tail[2] = bits(1.0f): max |raysat| of an image in which no ray saturates (raysat = -1)
+        e = hipMemsetD32Async((hipDeviceptr_t)(primlist_count + (size_t)N * K + 2), 0x3f800000, 1, st);
+        if (e != hipSuccess) return (int)e;
     }
     const bool fade8 = fadeexp == 8.0f;
     const dim3 grid((unsigned)p.total_packets), block(kWave);
