@@ -324,8 +324,9 @@ __device__ __forceinline__ bool lane_step_range(float tn, float tf, float tmin, 
                                                 int &hi) {
     const float ta = fmaxf(tn, tmin), tb = fminf(tf, tmax + 1e-5f);
     if (!(tn <= tf) || !(ta <= tb)) return false;
-    const float slack = 0.02f + 2.0e-6f * fmaxf(fmaxf(fabsf(ta), fabsf(tb)), 1.f) / dt;
-    const float flo = ceilf((ta - tmin) / dt - slack), fhi = floorf((tb - tmin) / dt + slack);
+    const float idt = fast_rcp(dt);  // the slack below is ~1e5 times the rounding this can add
+    const float slack = 0.02f + 2.0e-6f * fmaxf(fmaxf(fabsf(ta), fabsf(tb)), 1.f) * idt;
+    const float flo = ceilf((ta - tmin) * idt - slack), fhi = floorf((tb - tmin) * idt + slack);
     lo = (int)fminf(fmaxf(flo, 0.f), 1.0e9f);
     hi = (int)fminf(fmaxf(fhi, 0.f), 1.0e9f);
     return lo <= hi;
@@ -469,7 +470,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                     // 512-entry capacity (the pass below repeats it to get the step ranges)
                     const Rec q = rec_from_global(pp, pr, ps, node - (K - 1));
                     const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
-                    const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    const f3 ird = mk3(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
                     const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
                     const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
                     const bool hit = active && max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z)) <=
@@ -550,7 +551,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         const Rec q = (c < kRecSlots) ? rec_from_lds(s_rec, c) : rec_from_global(pp, pr, ps, k);
         const f3 r0 = rot_rows(q, o - q.pos) * q.scale;  // primtransf.h:134-153
         const f3 rd = rot_rows(q, d) * q.scale;
-        const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        const f3 ird = mk3(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
         const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
         const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
         const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
@@ -567,7 +568,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         if (__ballot(some) != 0ull) {  // wave-uniform
             const int wlo = uni(wave_min(lo)), whi = uni(wave_max(hi));
             if (whi >= 65535) ranges_ok = false;
-            __syncthreads();  // every lane has read s_b[c] before slot nh <= c is overwritten
+            // (slot nh <= c of s_b is overwritten below: the read of s_b[c] above was issued earlier by this same
+            //  wave -- the only one in the workgroup -- and LDS operations of a wave complete in order)
             if (nh < kMaxList) {
                 if (lane == 0) {
                     s_b[nh] = k | (slot << 24);
@@ -601,7 +603,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     rtmin = fmaxf(rtmin, tmin);  // subset_kernel.h:63-64
     rtmax = fminf(rtmax, tmax);
     const bool has = active && (rtmin < INFINITY) && nh > 0;
-    const int incs = has ? (int)fminf(floorf((rtmin - tmin) / dt), 1.0e9f) : 0x7fffffff;  // subset_kernel.h:70
+    const int incs = has ? (int)fminf(floorf((rtmin - tmin) * fast_rcp(dt)), 1.0e9f) : 0x7fffffff;  // subset_kernel.h:70
     const float tend = rtmax + 1e-5f;
 
     f3 dL3 = mk3(0.f, 0.f, 0.f);
@@ -637,7 +639,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             for (int j = lane; j < nh; j += kWave) mylast = max(mylast, ranges_ok ? ((s_a[j] >> 16) & 0xffff) : 0x7ffffffe);
             s_last = uni(wave_max(mylast));
             // no sample at or beyond t = tend: bound the sweep by the rays' own end as well
-            const int myend = has ? (int)fminf(floorf((tend - tmin) / dt) + 1.f, 1.0e9f) : -1;
+            const int myend = has ? (int)fminf(floorf((tend - tmin) * fast_rcp(dt)) + 1.f, 1.0e9f) : -1;
             s_last = min(s_last, uni(wave_max(myend)));
         }
         const int nchunks = (nh + kWave - 1) / kWave;
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     const int incs = (int)*at_bytes<uint32_t>(aux_n, r * 16u + 8u);
                     // the same formulas the forward used for the packet range [elo, ehi] (the union of these over lanes)
                     const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
-                    const f3 ird = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                    const f3 ird = mk3(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
                     const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
                     const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
                     const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));

@@ -101,6 +101,9 @@ __device__ __forceinline__ float uni(float v) {
 
 // v_exp_f32 / v_log_f32 (about 1 ulp); the reference uses the equivalent CUDA fast intrinsics
 // __expf / __powf (primsampler.h:48-51, built with -use_fast_math, extensions/mvpraymarch/setup.py:27)
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence; used where a conservative slack or the
+// exact inside test downstream absorbs the last bit (slab-interval tests, step-index ranges)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_exp(float x) { return fast_exp2(x * 1.44269504088896341f); }
