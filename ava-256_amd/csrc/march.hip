@@ -74,19 +74,65 @@ constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than
 constexpr uint32_t kFlagGlobal = 2u;        // a packet produced step indices that do not fit the packed keys
 constexpr uint32_t kNoSat = 0xffffffffu;
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
+
 struct Rec {  // one primitive's transform, wave-uniform while it is being processed
     f3 pos, r0, r1, r2, scale;
 };
 
+// LDS image of a record, 4 x float4 per list slot, ordered so that the 16-byte reads deliver the register PAIRS the
+// packed-fp32 box transform wants:  (r0.x r0.y r1.x r1.y) (r2.x r2.y pos.x pos.y) (r0.z r1.z r2.z pos.z) (s.x s.y s.z 0)
+__device__ __forceinline__ void rec_to_lds(float4 *s_rec, int slot, const Rec &q) {
+    s_rec[slot * 4 + 0] = make_float4(q.r0.x, q.r0.y, q.r1.x, q.r1.y);
+    s_rec[slot * 4 + 1] = make_float4(q.r2.x, q.r2.y, q.pos.x, q.pos.y);
+    s_rec[slot * 4 + 2] = make_float4(q.r0.z, q.r1.z, q.r2.z, q.pos.z);
+    s_rec[slot * 4 + 3] = make_float4(q.scale.x, q.scale.y, q.scale.z, 0.f);
+}
 __device__ __forceinline__ Rec rec_from_lds(const float4 *s_rec, int slot) {
     const float4 a = s_rec[slot * 4 + 0], b = s_rec[slot * 4 + 1], c = s_rec[slot * 4 + 2], d = s_rec[slot * 4 + 3];
     Rec r;
-    r.pos = mk3(a.x, a.y, a.z);
-    r.r0 = mk3(a.w, b.x, b.y);
-    r.r1 = mk3(b.z, b.w, c.x);
-    r.r2 = mk3(c.y, c.z, c.w);
+    r.pos = mk3(b.z, b.w, c.w);
+    r.r0 = mk3(a.x, a.y, c.x);
+    r.r1 = mk3(a.z, a.w, c.y);
+    r.r2 = mk3(b.x, b.y, c.z);
     r.scale = mk3(d.x, d.y, d.z);
     return r;
+}
+// The same record as register pairs: y = (R^T (x - pos)) * s in 10 VALU instructions (pk_add, sub, pk_mul, 2 pk_fma,
+// mul, 2 fma, pk_mul, mul) instead of 18 + the moves the compiler needs to build pairs out of f3 members.
+struct RecP {
+    v2f r0xy, r1xy, r2xy, pxy, sxy;
+    float r0z, r1z, r2z, pz, sz;
+};
+struct Y3 {
+    v2f xy;
+    float z;
+};
+__device__ __forceinline__ RecP recp_from_lds(const float4 *s_rec, int slot) {
+    const float4 a = s_rec[slot * 4 + 0], b = s_rec[slot * 4 + 1], c = s_rec[slot * 4 + 2], d = s_rec[slot * 4 + 3];
+    RecP r;
+    r.r0xy = v2f{a.x, a.y}, r.r1xy = v2f{a.z, a.w}, r.r2xy = v2f{b.x, b.y}, r.pxy = v2f{b.z, b.w};
+    r.r0z = c.x, r.r1z = c.y, r.r2z = c.z, r.pz = c.w;
+    r.sxy = v2f{d.x, d.y}, r.sz = d.z;
+    return r;
+}
+__device__ __forceinline__ RecP recp_of(const Rec &q) {
+    RecP r;
+    r.r0xy = v2f{q.r0.x, q.r0.y}, r.r1xy = v2f{q.r1.x, q.r1.y}, r.r2xy = v2f{q.r2.x, q.r2.y};
+    r.pxy = v2f{q.pos.x, q.pos.y}, r.sxy = v2f{q.scale.x, q.scale.y};
+    r.r0z = q.r0.z, r.r1z = q.r1.z, r.r2z = q.r2.z, r.pz = q.pos.z, r.sz = q.scale.z;
+    return r;
+}
+// primtransf.h:119-132 for a direction (no translation) and for a point
+__device__ __forceinline__ Y3 box_dir(const RecP &q, v2f vxy, float vz) {
+    Y3 y;
+    y.xy = (q.r0xy * vxy.x + q.r1xy * vxy.y + q.r2xy * vz) * q.sxy;
+    y.z = (q.r0z * vxy.x + q.r1z * vxy.y + q.r2z * vz) * q.sz;
+    return y;
+}
+__device__ __forceinline__ Y3 box_point(const RecP &q, v2f xxy, float xz) { return box_dir(q, xxy - q.pxy, xz - q.pz); }
+__device__ __forceinline__ bool strictly_inside(const Y3 &y) {  // primtransf.h:112-117
+    return fabsf(y.xy.x) < 1.f && fabsf(y.xy.y) < 1.f && fabsf(y.z) < 1.f;
 }
 __device__ __forceinline__ Rec rec_from_global(const float *pp, const float *pr, const float *ps, int k) {
     Rec r;
@@ -151,8 +197,6 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d)
     a.sgn = allpos ? 1 : (allneg ? -1 : 0);
     return a;
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
 
 // One ray packet (8x8 pixels, one wave).  s_a: frontier ping, later packed step ranges (lo | hi << 16);
 // s_b: frontier pong / candidate list / final list (k | slot << 24); s_rec: SRT records of the first 64 candidates.
@@ -531,26 +575,23 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             }
             // stage the SRT records of the first 64 candidates: lanes over candidates, one gather round trip
             if (lane < ncand && lane < kRecSlots) {
-                const Rec q = rec_from_global(pp, pr, ps, kk[0]);
-                s_rec[lane * 4 + 0] = make_float4(q.pos.x, q.pos.y, q.pos.z, q.r0.x);
-                s_rec[lane * 4 + 1] = make_float4(q.r0.y, q.r0.z, q.r1.x, q.r1.y);
-                s_rec[lane * 4 + 2] = make_float4(q.r1.z, q.r2.x, q.r2.y, q.r2.z);
-                s_rec[lane * 4 + 3] = make_float4(q.scale.x, q.scale.y, q.scale.z, 0.f);
+                rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk[0]));
             }
             __syncthreads();
         }
     }
 
     if (p.debug_stage == 1) ncand = 0;
+    const v2f oxy = {o.x, o.y}, dxy = {d.x, d.y};
     // ---------------- exact per-ray leaf test (utils.h:744-761), lanes over rays ----------------
     float rtmin = INFINITY, rtmax = -INFINITY;
     bool ranges_ok = true;  // false when a step index does not fit the packed 16-bit range
     for (int c = 0; c < ncand; ++c) {
         const int k = uni(s_b[c]);
         const int slot = c < kRecSlots ? c : kNoSlot;
-        const Rec q = (c < kRecSlots) ? rec_from_lds(s_rec, c) : rec_from_global(pp, pr, ps, k);
-        const f3 r0 = rot_rows(q, o - q.pos) * q.scale;  // primtransf.h:134-153
-        const f3 rd = rot_rows(q, d) * q.scale;
+        const RecP q = (c < kRecSlots) ? recp_from_lds(s_rec, c) : recp_of(rec_from_global(pp, pr, ps, k));
+        const Y3 r0p = box_point(q, oxy, o.z), rdp = box_dir(q, dxy, d.z);  // primtransf.h:134-153
+        const f3 r0 = mk3(r0p.xy.x, r0p.xy.y, r0p.z), rd = mk3(rdp.xy.x, rdp.xy.y, rdp.z);
         const f3 ird = mk3(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
         const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
         const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
@@ -651,7 +692,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         while (s <= s_last) {
             if (__ballot(has && !sat) == 0ull) break;  // every ray saturated (subset_kernel.h:76)
             const float t = fmaf((float)s, dt, tmin);
-            const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+            const v2f xxy = dxy * t + oxy;
+            const f3 x = mk3(xxy.x, xxy.y, fmaf(d.z, t, o.z));
             const bool inrange = has && s >= incs && t < tend;
             bool anyslot = false;
             int nextlo = 0x7fffffff;
@@ -678,11 +720,9 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                         m &= m - 1ull;
                         const int ent = ch == 0 ? __builtin_amdgcn_readlane(ent0, bit) : uni(s_b[ch * kWave + bit]);
                         const int slot = (ent >> 24) & 0xff;
-                        const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot)
-                                                         : rec_from_global(pp, pr, ps, ent & 0xffffff);
-                        const f3 y = rot_rows(q, x - q.pos) * q.scale;
-                        const bool inside = inrange && !sat && y.x > -1.f && y.x < 1.f && y.y > -1.f && y.y < 1.f &&
-                                            y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
+                        const RecP q = (slot != kNoSlot) ? recp_from_lds(s_rec, slot)
+                                                          : recp_of(rec_from_global(pp, pr, ps, ent & 0xffffff));
+                        const bool inside = inrange && !sat && strictly_inside(box_point(q, xxy, x.z));  // subset_kernel.h:84
                         if (inside) mine |= 1ull << bit;
                     }
                     if (p.debug_stage == 3) mine = 0ull;
@@ -696,8 +736,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             // Opaque on purpose: with the TS > 0 sampler below, hipcc (ROCm 7.2) dropped this mask and fed
                             // the raw entry (slot bits included) to the 64-bit address of the record loads -> wild reads.
                             asm volatile("; k = entry & 0xffffff" : "+v"(k));
-                            const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
-                            const f3 y = rot_rows(q, x - q.pos) * q.scale;
+                            const RecP q = (slot != kNoSlot) ? recp_from_lds(s_rec, slot)
+                                                              : recp_of(rec_from_global(pp, pr, ps, k));
+                            const Y3 yp = box_point(q, xxy, x.z);
+                            const f3 y = mk3(yp.xy.x, yp.xy.y, yp.z);
                             float4 v;
                             if (WARP) {  // primsampler.h:48-63 with dowarp: fade from y0, template sampled at warp(y0)
                                 const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
