@@ -31,7 +31,11 @@ SIGNATURES = {
 }
 SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
-ABI_VERSION = 3
+# ntensors | grads(host array of device ptrs), numels(host array) | sqnorm | stream
+SIGNATURES["mvp_grads_sanitize_sqnorm"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_void_p])
+# ntensors | grads, numels | sqnorm | max_norm | total_norm | stream
+SIGNATURES["mvp_grads_clip_scale"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 2)
+ABI_VERSION = 4
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -108,6 +108,8 @@ class Trainer:
         self.clip = clip
         self.loss_weights = loss_weights or {"irgbl1": 1.0, "primvolsum": 0.01}  # configs/config.yaml:17-21
         self.iternum = 0
+        self._clipper = None
+        self.last_grad_norm = None
 
     def losses(self, output, batch):
         out = {}
@@ -124,12 +126,20 @@ class Trainer:
         loss = sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
         self.optim.zero_grad(set_to_none=False)
         loss.backward()
-        # NaN / Inf -> 0 in every gradient (ddp-train.py:436-439 does two masked assignments per tensor, ~600 host
-        # syncs per iteration on ava-256; nan_to_num_ is the same mapping without the syncs)
-        for p in self.params:
-            if p.grad is not None:
-                p.grad.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
-        torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+        # NaN / Inf -> 0 in every gradient, then clip the global 2-norm (ddp-train.py:436-441: two masked assignments
+        # per tensor -- ~600 host syncs per iteration on ava-256 -- and clip_grad_norm_).  On the GPU both are two
+        # multi-tensor HIP passes with the coefficient computed on the device (gradclip.py); the
+        # eager statements remain only for the CPU host-logic tests, where no kernel of this package can run.
+        if self.params and self.params[0].is_cuda:
+            if self._clipper is None:
+                from .gradclip import GradClipper
+                self._clipper = GradClipper(self.params[0].device)
+            self.last_grad_norm = self._clipper(self.params, self.clip)
+        else:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
+            self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.optim.step()
         self.sched.step()
         self.iternum += 1

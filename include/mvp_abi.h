@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 3
+#define MVP_ABI_VERSION 4
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -120,6 +120,21 @@ int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const 
                                   void *stream);
 int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
                                    float *grad_tex, float *grad_opacity, void *stream);
+
+/* Gradient hygiene of the optimisation loop as two multi-tensor passes.  Replaces, per
+ * iteration, the per-parameter eager sequence of /root/reference/ddp-train.py:434-441:
+ *     p.grad.data[torch.isnan(p.grad.data)] = 0 ; p.grad.data[torch.isinf(p.grad.data)] = 0   (for every parameter)
+ *     torch.nn.utils.clip_grad_norm_(model.parameters(), clip)      (PyTorch: 2-norm of the per-tensor 2-norms,
+ *                                                                     coef = min(1, clip / (norm + 1e-6)))
+ * `grads` and `numels` are HOST arrays of `ntensors` device pointers (float32, 4-byte aligned, dense) and element
+ * counts; they are read during the call only.  `sqnorm` is one double in DEVICE memory owned by the caller.
+ *   mvp_grads_sanitize_sqnorm : non-finite elements become 0 in place; *sqnorm = sum of squares of the result.
+ *   mvp_grads_clip_scale      : coef from *sqnorm on the device (no host sync); grads *= coef when coef < 1;
+ *                               *total_norm (device float, may be NULL) = sqrt(*sqnorm). */
+int mvp_grads_sanitize_sqnorm(int ntensors, float *const *grads, const long long *numels, double *sqnorm,
+                              void *stream);
+int mvp_grads_clip_scale(int ntensors, float *const *grads, const long long *numels, const double *sqnorm,
+                         float max_norm, float *total_norm /*or NULL*/, void *stream);
 
 #ifdef __cplusplus
 }
