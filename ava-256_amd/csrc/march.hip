@@ -1190,8 +1190,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long lt = lanemask_lt(lane);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int K = p.K;
     // XCD-aware: block b runs on XCD b % 8; give each XCD a contiguous range of k (neighbours on the shell share rays)
     const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
@@ -1202,8 +1201,23 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     const size_t pk = (size_t)n * K + k;
     uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] bits(G), [2] bits(Rmax)
 
-    const uint32_t flags = tail[0];
-    const uint32_t cnt = p.pl_count[pk];
+    // Everything this workgroup needs first is requested at once, before any of it is looked at: flags, list length,
+    // the primitive's transform (scalar loads: wave-uniform addresses, data no kernel in flight writes) and -- for the
+    // 8^3 instantiation -- this thread's two slab voxels, speculatively (an empty list is rare and the read is valid
+    // either way).  The former order (counter -> branch -> slab -> barrier -> transform) cost two more dependent
+    // global round trips per workgroup.
+    const uint32_t flags = cload(tail);
+    const uint32_t cnt = cload(p.pl_count + pk);
+    const float *qp = p.primpos + pk * 3, *qr = p.primrot + pk * 9, *qs = p.primscale + pk * 3;
+    Rec q;  // SGPRs
+    q.pos = mk3(cload(qp), cload(qp + 1), cload(qp + 2));
+    q.r0 = mk3(cload(qr), cload(qr + 1), cload(qr + 2));
+    q.r1 = mk3(cload(qr + 3), cload(qr + 4), cload(qr + 5));
+    q.r2 = mk3(cload(qr + 6), cload(qr + 7), cload(qr + 8));
+    q.scale = mk3(cload(qs), cload(qs + 1), cload(qs + 2));
+    const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
+    float4 tv0 = make_float4(0.f, 0.f, 0.f, 0.f), tv1 = tv0;
+    if (TS == 8) tv0 = T4[tid], tv1 = T4[tid + kPrimBlock];
     float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
@@ -1211,11 +1225,16 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     // ---- stage the slab and its max |rgb| ----
     float tmax = 0.f;
     if (!dead && cnt > 0u) {
-        const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
-        for (int v = tid; v < V; v += kPrimBlock) {
-            const float4 t = T4[v];
-            s_T[v] = t;
-            tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
+        if (TS == 8) {
+            s_T[tid] = tv0, s_T[tid + kPrimBlock] = tv1;
+            tmax = fmaxf(fmaxf(fmaxf(fabsf(tv0.x), fabsf(tv0.y)), fabsf(tv0.z)),
+                         fmaxf(fmaxf(fabsf(tv1.x), fabsf(tv1.y)), fabsf(tv1.z)));
+        } else {
+            for (int v = tid; v < V; v += kPrimBlock) {
+                const float4 t = T4[v];
+                s_T[v] = t;
+                tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
+            }
         }
         for (int v = tid; v < 4 * Vp; v += kPrimBlock) {
             s_hi[v] = 0;
@@ -1229,7 +1248,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     float s_rgb = 0.f, s_a = 0.f;
     if (!dead && cnt > 0u) {
         tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        const float G = __uint_as_float(tail[1]), Rmax = __uint_as_float(tail[2]);
+        const float G = __uint_as_float(cload(tail + 1)), Rmax = __uint_as_float(cload(tail + 2));
         // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
         const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
         if (G == 0.f) {
@@ -1253,15 +1272,6 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         if (tid < 3) p.grad_primpos[pk * 3 + tid] = 0.f;
         return;
     }
-    Rec q = rec_from_global(p.primpos + (size_t)n * K * 3, p.primrot + (size_t)n * K * 9,
-                            p.primscale + (size_t)n * K * 3, k);
-    // block-uniform, but loaded with vector loads (the kernel also stores, so the compiler will not use s_load):
-    // move the 15 words to SGPRs
-    q.pos = mk3(uni(q.pos.x), uni(q.pos.y), uni(q.pos.z));
-    q.r0 = mk3(uni(q.r0.x), uni(q.r0.y), uni(q.r0.z));
-    q.r1 = mk3(uni(q.r1.x), uni(q.r1.y), uni(q.r1.z));
-    q.r2 = mk3(uni(q.r2.x), uni(q.r2.y), uni(q.r2.z));
-    q.scale = mk3(uni(q.scale.x), uni(q.scale.y), uni(q.scale.z));
 
     const float dt = p.stepsize;
     // per-image base pointers are wave-uniform (SGPR pairs); rays are addressed with a 32-bit index inside the image,
@@ -1307,7 +1317,8 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             ticket[u] = 0u;
             item[u] = make_uint4(0u, 0u, 0u, 0u);
             if (e < eend) {
-                const uint2 ent = list[e];
+                const uint32_t *lw = reinterpret_cast<const uint32_t *>(list + e);  // wave-uniform: scalar loads
+                const uint2 ent = make_uint2(cload(lw), cload(lw + 1));
                 const int tidx = (int)(ent.x >> 9);
                 const uint32_t slot = ent.x & 511u;
                 const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);

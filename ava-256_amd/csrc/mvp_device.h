@@ -101,6 +101,13 @@ __device__ __forceinline__ float uni(float v) {
 
 // v_exp_f32 / v_log_f32 (about 1 ulp); the reference uses the equivalent CUDA fast intrinsics
 // __expf / __powf (primsampler.h:48-51, built with -use_fast_math, extensions/mvpraymarch/setup.py:27)
+// Load through the constant address space: with a wave-uniform address this is an s_load (result in SGPRs, no VGPR
+// and no vector-memory slot).  Only for data no kernel in flight writes (inputs, the previous kernel's outputs).
+template <class T>
+__device__ __forceinline__ T cload(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence; used where a conservative slack or the
 // exact inside test downstream absorbs the last bit (slab-interval tests, step-index ranges)
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
