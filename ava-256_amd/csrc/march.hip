@@ -67,7 +67,8 @@ struct MarchParams {
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
     int total_packets;    // 8 * chunk * N
     int debug_force_dfs;  // tests: MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
-    int debug_stage;      // profiling only: MVP_DEBUG_STAGE=1 stop after traversal, 2 after the exact pass, 3 no sampling
+    int debug_stage;      // profiling only (MVP_DEBUG_STAGE): 11 stop after the root test, 12 after the ancestor pre-cull,
+                          // 13 after the implicit level, 1 after traversal, 2 after the exact pass, 3 no sampling
 };
 
 constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than pl_cap packets
