@@ -1416,9 +1416,11 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             __syncthreads();
         }
         pending += round_samples;  // <= kFixMaxSamples by the guard above
-        // ---------------- phase 2: the queued rays, split evenly over the 4 waves ----------------
+        // ---------------- phase 2: the queued rays in chunks of 64, dealt to the 4 waves ----------------
+        // Full chunks, even when that leaves waves without work: the longest ray sets the round's critical path either
+        // way, and 2 waves x 64 lanes issue half the instructions (VALU and LDS atomics) of 4 waves x 32 lanes.
         const int nq = (int)*s_qn;
-        const int per = min(kWave, (nq + 3) >> 2);
+        const int per = kWave;
         for (int qb = wave * per; qb < nq; qb += 4 * per) {
             // queue neighbours are usually neighbouring pixels, i.e. rays in the same slab cell: put them in DIFFERENT
             // 32-lane halves so that their LDS atomics to the same address do not meet in one pass
