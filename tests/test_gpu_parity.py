@@ -386,6 +386,57 @@ def test_reference_extension_shape_test(ops):
     assert d["packets_hit"] == 0 and float(rayalpha.abs().max()) == 0.0
 
 
+def test_drop_in_boundary_matches_reference_glue(ops):
+    """The drop-in claim itself (oracle O2).  tests/golden/boundary_raymarcher.npz holds what the
+    REFERENCE'S OWN Python glue (compute_raydirs, mvpraymarch/MVPRaymarch/build_accel, Raymarcher -- imported unmodified
+    from the reference tree) returns when its two native modules are float64 stand-ins with the reference's positional
+    signatures: rays, (rayrgb, rayalpha) in NCHW, and the gradients of the decoder outputs for a weighted-sum loss,
+    with renderoptions that carry an option of mvpraymarch (fadescale=6) and a key it does not know.  Here the same
+    inputs go through THIS build, imported through the reference's import paths."""
+    from extensions.utils.utils import compute_raydirs          # models/autoencoder.py:19
+    from models.raymarchers.mvpraymarcher import Raymarcher     # models/autoencoder.py:20
+    from ava256_amd import _hooks as mm
+    g = np.load(os.path.join(GOLDEN, "boundary_raymarcher.npz"))
+    assert list(g["calls"])[:2] == ["compute_raydirs_forward", "compute_aabb"]  # the call order the glue produced
+    cam = [to_dev(g["in_" + k]) for k in ("campos", "camrot", "focal", "princpt", "pixelcoords")]
+    volradius = float(g["volradius"])
+    raypos, raydir, tminmax = compute_raydirs(*cam, volradius)
+    for name, t in (("raypos", raypos), ("raydir", raydir), ("tminmax", tminmax)):
+        assert np.abs(npf(t) - g[name]).max() <= 2e-6 * max(1.0, np.abs(g[name]).max()), name
+    decout = {k: to_dev(g["in_" + k]).requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
+    renderoptions = {"fadescale": 6.0, "fadeexp": 8.0, "not_an_option_of_mvpraymarch": 123}
+    assert sorted(renderoptions) == list(g["renderoptions_keys"])
+    mm.keep_raysat = True
+    rm = Raymarcher(volradius, dt=float(g["dt"]))
+    assert len(list(rm.parameters())) == 0 and len(list(rm.buffers())) == 0  # checkpoints load unchanged
+    rayrgb, rayalpha, rayrgba, pos_img = rm(raypos, raydir, tminmax, decout, renderoptions=renderoptions)
+    assert pos_img is None and tuple(rayrgba.shape) == tuple(g["rayrgba_view_shape"])
+    assert rayrgb.is_contiguous() and rayalpha.is_contiguous()
+    tol = 2e-4 * max(1.0, np.abs(g["rayrgb"]).max())
+    assert np.abs(npf(rayrgb) - g["rayrgb"]).max() <= tol
+    assert np.abs(npf(rayalpha) - g["rayalpha"]).max() <= 2e-4
+    # gradients: rays whose saturation state differs from the float64 run by fp32 round-off are left out of the loss
+    sat_ref = g["rayalpha"][:, 0] >= 1.0 - 1e-12
+    sat_here = npf(mm.last_raysat)[..., 0] > -1.0
+    agree = torch.from_numpy((sat_ref == sat_here)[:, None].astype(np.float32)).cuda()
+    assert float(agree.mean()) > 0.97
+    w_rgb, w_a = to_dev(g["w_rgb"]), to_dev(g["w_a"])
+    if float(agree.min()) == 1.0:
+        loss = (rayrgb * w_rgb).sum() + (rayalpha * w_a).sum()
+        loss.backward()
+        assert abs(float(loss) - float(g["loss"])) <= 2e-4 * max(1.0, abs(float(g["loss"])))
+        for k in ("template", "primpos", "primrot", "primscale"):
+            got, ref = npf(decout[k].grad), g["grad_" + k]
+            if k == "template":
+                assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), k
+            else:
+                assert cosine(got, ref) >= 0.9999, k
+                assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max(), k
+    else:  # (not expected for this fixture) compare on the agreeing rays through the oracle instead
+        pytest.skip("saturation state differs on some rays: gradient comparison needs the masked loss")
+    mm.keep_raysat = False
+
+
 def test_operator_errors(ops):
     """Error behaviour at the boundary: CPU tensors, wrong dtype, non-contiguous input, unsupported options."""
     from ava256_amd.scene import make_scene

@@ -87,3 +87,34 @@ def test_oracle_aabb_contains_boxes(oracle64):
         for i in range(K - 1):
             assert np.all(A[n, i, 0] == np.minimum(A[n, 2 * i + 1, 0], A[n, 2 * i + 2, 0]))
             assert np.all(A[n, i, 1] == np.maximum(A[n, 2 * i + 1, 1], A[n, 2 * i + 2, 1]))
+
+
+def test_boundary_fixture_is_the_oracle_behind_the_reference_glue(oracle64):
+    """tests/golden/boundary_raymarcher.npz was produced by the reference's unmodified Python glue around float64
+    stand-ins of its native modules (tests/golden/gen_boundary.py).  Re-deriving its outputs from the oracle alone pins
+    what the glue adds: stepsize = dt / volradius (mvpraymarcher.py:24), only options that are parameters of
+    mvpraymarch pass the renderoptions filter (:45) -- fadescale=6 arrived, the unknown key did not --, and the
+    result is the [N,H,W,4] march output permuted to NCHW and split 3 + 1 (:50-51)."""
+    g = np.load(os.path.join(GOLDEN, "boundary_raymarcher.npz"))
+    calls = list(g["calls"])
+    assert calls == ["compute_raydirs_forward", "compute_aabb", "raymarch_forward fadescale=6 fadeexp=8 algo=0 chlast=True",
+                     "raymarch_backward"]
+    rp, rd, tm = oracle64.raydirs(g["in_campos"], g["in_camrot"], g["in_focal"], g["in_princpt"], g["in_pixelcoords"],
+                                  float(g["volradius"]))
+    np.testing.assert_allclose(rp, g["raypos"], atol=1e-12)
+    np.testing.assert_allclose(rd, g["raydir"], atol=1e-12)
+    np.testing.assert_allclose(tm, g["tminmax"], atol=1e-12)
+    stepsize = float(g["dt"]) / float(g["volradius"])
+    args = (rp, rd, stepsize, tm, g["in_primpos"], g["in_primrot"], g["in_primscale"], g["in_template"])
+    rgba, sat, st = oracle64.march_forward(*args, fadescale=6.0, fadeexp=8.0)
+    np.testing.assert_allclose(np.transpose(rgba, (0, 3, 1, 2))[:, :3], g["rayrgb"], atol=1e-12)
+    np.testing.assert_allclose(np.transpose(rgba, (0, 3, 1, 2))[:, 3:4], g["rayalpha"], atol=1e-12)
+    assert 0.3 < st["rays_saturated"] / (rgba.shape[0] * rgba.shape[1] * rgba.shape[2]) < 0.8
+    gout = np.concatenate([g["w_rgb"], g["w_a"]], axis=1).transpose(0, 2, 3, 1)  # d loss / d rayrgba, NHWC
+    gp, gr, gs, gt = oracle64.march_backward(*args, sat, np.ascontiguousarray(gout), fadescale=6.0, fadeexp=8.0)
+    for got, k in ((gp, "primpos"), (gr, "primrot"), (gs, "primscale"), (gt, "template")):
+        # (the glue allocates raysat and nodeaabb as float32 whatever the default dtype: mvpraymarch.py:81,146-148)
+        np.testing.assert_allclose(got, g["grad_" + k], rtol=1e-5, atol=1e-6 * np.abs(g["grad_" + k]).max())
+    # with the default fadescale the image differs: the option really went through the filter
+    rgba8, _, _ = oracle64.march_forward(*args, fadescale=8.0, fadeexp=8.0)
+    assert np.abs(rgba8 - rgba).max() > 1e-3
