@@ -77,7 +77,8 @@ class RaymarchTrainModel(nn.Module):
         self.raymarcher = Raymarcher(volradius, dt)
         self._renderer = renderer  # CPU tests inject a pure-torch stand-in; None = the gfx950 kernels
 
-    def forward(self, camrot, campos, focal, princpt, pixelcoords, code):
+    def forward(self, camrot, campos, focal, princpt, pixelcoords, code, schedule=None):
+        self.last_schedule = schedule  # ddp-train.py:371-377; consumed by a real decoder's geometry branch
         decout = self.decoder(code)
         if self._renderer is not None:
             rayrgb, rayalpha = self._renderer(camrot, campos, focal, princpt, pixelcoords, decout)
@@ -86,6 +87,15 @@ class RaymarchTrainModel(nn.Module):
                                                       self.raymarcher.volume_radius)
             rayrgb, rayalpha, _, _ = self.raymarcher(raypos, raydir, tminmax, decout)
         return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"]}
+
+
+def forward_schedule(iternum: int) -> Dict[str, object]:
+    """Forward-pass switches of the first iterations, ddp-train.py:371-377: for iternum < 100 the decoder is driven
+    with `running_avg_scale=True`, ground-truth geometry (`gt_geo = verts`) and `residuals_weight = 0`; afterwards
+    `False`, `None`, `1.0`.  Returned as (running_avg_scale, use_gt_geo, residuals_weight); the Trainer hands them to a
+    model whose forward takes a `schedule` keyword (the stand-in decoder has no geometry branch and ignores them)."""
+    warm = iternum < 100
+    return {"running_avg_scale": warm, "use_gt_geo": warm, "residuals_weight": 0.0 if warm else 1.0}
 
 
 class Trainer:
@@ -121,7 +131,7 @@ class Trainer:
 
     def step(self, batch: Dict[str, torch.Tensor]):
         output = self.model(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
-                            batch["code"])
+                            batch["code"], schedule=forward_schedule(self.iternum))
         losses = self.losses(output, batch)
         loss = sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
         self.optim.zero_grad(set_to_none=False)

@@ -55,6 +55,22 @@ def test_loop_semantics_cpu():
     assert tot <= 1.0 + 1e-4
 
 
+def test_forward_schedule_of_the_first_iterations():
+    """ddp-train.py:371-377: running_avg_scale / gt_geo / residuals_weight switch at iteration 100."""
+    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer, forward_schedule
+    assert forward_schedule(0) == {"running_avg_scale": True, "use_gt_geo": True, "residuals_weight": 0.0}
+    assert forward_schedule(99) == forward_schedule(0)
+    assert forward_schedule(100) == {"running_avg_scale": False, "use_gt_geo": False, "residuals_weight": 1.0}
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer)
+    tr = Trainer(model)
+    b = _batch(2, 8, 8, 0)
+    tr.step(b)
+    assert model.last_schedule == forward_schedule(0)
+    tr.iternum = 100
+    tr.step(b)
+    assert model.last_schedule == forward_schedule(100) and tr.iternum == 101
+
+
 def test_nan_and_inf_gradients_are_zeroed():
     """ddp-train.py:436-439: NaN/Inf gradient entries become 0 before clipping and the optimiser step."""
     from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer
