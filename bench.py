@@ -31,6 +31,7 @@ WORKLOADS = {
     "C2": (80, 512, 512, 4096, 8),
     "C3": (4, 512, 512, 16384, 8),
     "C1": (4, 128, 128, 512, 8),
+    "C4": (4, 1024, 1024, 8192, 8),
 }
 
 
