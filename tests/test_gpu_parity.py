@@ -167,6 +167,45 @@ def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg, mode):
     _check_grads(grads, ref, str(cfg))
 
 
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+@pytest.mark.parametrize("shape,fadescale,fadeexp", [((4, 6, 5), 5.0, 6.0), ((8, 8, 8), 7.0, 3.0), ((3, 2, 7), 8.0, 8.0)])
+def test_non_cubic_slabs_and_general_fade(ops, oracle64, shape, fadescale, fadeexp, mode):
+    """The template's (TD, TH, TW) come from the tensor (mvpraymarch.cpp:233-238) and need not be equal; fadeexp != 8
+    takes the pow form of the fade and of its derivative (primsampler.h:48-51,70-74).  Covers the generic-stride
+    instantiations of both kernels with either fade, and the 8^3 one with the general fade."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 2, 40, 48, 96
+    s = make_scene(N, H, W, K, device="cpu", seed=31, alpha_gain=3.0, slab=4)
+    s["primscale"] = s["primscale"] * 0.7
+    rng = np.random.default_rng(17)
+    TD, TH, TW = shape
+    tpl = np.concatenate([np.maximum(100 + 25 * rng.normal(size=(N, K, TD, TH, TW, 3)), 0),
+                          3.0 * np.exp(0.1 * rng.normal(size=(N, K, TD, TH, TW, 1)))], axis=-1)
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), tpl)
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, fadescale=fadescale, fadeexp=fadeexp)
+    assert st["rays_hit"] > 0 and st["list_overflow"] == 0
+    gout = rng.normal(size=ref_rgba.shape)
+    fragile = {}
+
+    def masked_gout(hip_raysat):
+        diff = np.abs(hip_raysat - ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(ref_sat).max())
+        fragile["mask"] = diff
+        g = gout.copy()
+        g[diff] = 0.0
+        return g
+
+    rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=masked_gout, mode=mode)
+    fr = fragile["mask"]
+    assert fr.sum() <= max(2, 0.005 * fr.size), fr.sum()
+    g2 = gout.copy()
+    g2[fr] = 0.0
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, g2, fadescale=fadescale, fadeexp=fadeexp)
+    err = np.abs(rgba - ref_rgba).max(-1)
+    assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0, err[~fr].max()
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), str(shape))
+
+
 @pytest.mark.parametrize("name", ["march_warp_k8_m8", "march_warp_k8_m8_sat"])
 def test_warp_sampler_matches_reference_golden(ops, name):
     """algo 1 (PrimSamplerTW<true>): fixtures from the reference's gradcheck(dowarp=True) dense loop (float64)."""
