@@ -1,3 +1,4 @@
+# Test infrastructure (uses the oracle as the checker): reproduces the heavy-scene traversal fallback outside pytest.
 import sys, os, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import ava256_amd as ops
