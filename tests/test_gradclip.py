@@ -8,7 +8,7 @@ import torch
 
 from oracle.gradclip_oracle import sanitize_and_clip
 
-SIZES = [1, 3, 4, 5, 63, 64, 65, 1000, 16384, 16385, 40001, 3 * 16384 + 7, 200000]
+SIZES = [1, 3, 4, 5, 63, 64, 65, 1000, 16384, 16385, 40001, 65536, 65537, 3 * 65536 + 7, 200000]
 
 
 def make_grads(seed, sizes=SIZES, scale=1.0, bad=True):
