@@ -19,7 +19,7 @@ class GradClipper:
         self.device = torch.device(device)
         self._sq = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self._cache = None  # (gradient tensors, pointer table, element counts) of the previous call
+        self._cache = None  # (addresses + sizes, pointer table, element counts) of the previous call
 
     @staticmethod
     def _grads_of(items):
@@ -41,14 +41,14 @@ class GradClipper:
         grads = self._grads_of(params_or_grads)
         lib = _lib.get_lib()
         n = len(grads)
-        # the pointer table is rebuilt only when the set of gradient tensors changed (zero_grad(set_to_none=False) and
-        # DDP's bucket views keep them; 600 data_ptr() calls cost more than both kernels)
+        # the ctypes tables are rebuilt only when an address or a size changed (zero_grad(set_to_none=False) and DDP's
+        # bucket views keep them)
+        key = [g.data_ptr() for g in grads] + [g.numel() for g in grads]
         c = self._cache
-        if c is None or len(c[0]) != n or any(a is not b for a, b in zip(c[0], grads)) or \
-                any(g.data_ptr() != p for g, p in zip(grads[:4], c[1][:4])):
-            ptrs = (ctypes.c_void_p * max(n, 1))(*[g.data_ptr() for g in grads])
-            numels = (ctypes.c_longlong * max(n, 1))(*[g.numel() for g in grads])
-            self._cache = c = (grads, ptrs, numels)
+        if c is None or c[0] != key:
+            ptrs = (ctypes.c_void_p * max(n, 1))(*key[:n])
+            numels = (ctypes.c_longlong * max(n, 1))(*key[n:])
+            self._cache = c = (key, ptrs, numels)
         ptrs, numels = c[1], c[2]
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
