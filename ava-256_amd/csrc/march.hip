@@ -77,6 +77,12 @@ constexpr uint32_t kNoSat = 0xffffffffu;
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
 
+// Raise flag bits in a shared word without queueing behind every other wave that raises the same bits (same-address
+// atomics serialise in L2; a stale read only costs one redundant atomic)
+__device__ __forceinline__ void raise_flag(uint32_t *word, uint32_t bits) {
+    if ((__atomic_load_n(word, __ATOMIC_RELAXED) & bits) != bits) atomicOr(word, bits);
+}
+
 struct Rec {  // one primitive's transform, wave-uniform while it is being processed
     f3 pos, r0, r1, r2, scale;
 };
@@ -636,9 +642,9 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             if (idx < (uint32_t)p.pl_cap)
                 p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j]);
             else
-                atomicOr(flags, kFlagListOverflow);
+                raise_flag(flags, kFlagListOverflow);
         }
-        if (!ranges_ok && lane == 0) atomicOr(flags, kFlagGlobal);
+        if (!ranges_ok && lane == 0) raise_flag(flags, kFlagGlobal);
     }
 
     // ---------------- march ----------------
@@ -1273,7 +1279,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
             if (tid == 0) {
                 p.pl_count[pk] = 0xffffffffu;
-                atomicOr(tail, kFlagListOverflow);
+                raise_flag(tail, kFlagListOverflow);
             }
         } else {
             s_rgb = fix_scale(Brgb) * 65536.f;  // value -> int(value * s): 16 fractional bits
@@ -1384,7 +1390,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         if (s_qn[2] != 0u || s_qn[1] > kFixMaxSamples) {
             if (tid == 0) {
                 p.pl_count[pk] = 0xffffffffu;
-                atomicOr(tail, kFlagListOverflow);
+                raise_flag(tail, kFlagListOverflow);
             }
             // (addresses re-derived from a laundered pk: this exit sits inside the march loop and would otherwise keep
             //  the output pointers of the zero-fill live -- and spilled -- through the whole loop)
