@@ -8,6 +8,7 @@ Only what the path needs lives here:
   mvpraymarch.py   mvpraymarch / MVPRaymarch / build_accel   (reference: extensions/mvpraymarch/mvpraymarch.py:21-390)
   raymarcher.py    Raymarcher nn.Module                      (reference: models/raymarchers/mvpraymarcher.py:17-54)
   assemble.py      fused decoder -> raymarch template assembly  (rgb.py:137-143, assembler.py:261)
+  placement.py     primitive placement on the mesh, 3 texels per primitive (row N2; assembler.py:118-122,143-206)
   gradclip.py      multi-tensor NaN/Inf masking + gradient clipping (row N4; ddp-train.py:434-441)
   trainloop.py     the reference-shaped optimisation loop around the operators (ddp-train.py:362-442), stand-in decoder
   dist_util.py     one-process-per-GPU helpers (camera sharding, RCCL/gloo init)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 4
+#define MVP_ABI_VERSION 5
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -120,6 +120,25 @@ int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const 
                                   void *stream);
 int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
                                    float *grad_tex, float *grad_opacity, void *stream);
+
+/* Primitive placement on the mesh (the barycentric half of SURVEY.md 8f row N2).  Replaces the eager expression of
+ * /root/reference/models/decoders/assembler.py:118-122 -- a 1024 x 1024 x 3 position map per batch element from three
+ * index_selects of [B, 1048576, 3] -- together with the only reads the assembler makes of that map
+ * (assembler.py:143-206): the texel at each primitive's centre and its +u / +v neighbours.
+ *   geo [B,V,3] float32 (already de-normalised: geo * vertstd + vertmean, assembler.py:101)
+ *   idxim [T,T,3] int32 vertex indices, barim [T,T,3] float32 barycentric weights (assembler.py:61-64)
+ *   centre of primitive k = i*nx + j is the texel (y0 + i*sy, x0 + j*sx); e.g. 16384 primitives: ny = nx = 128,
+ *   y0 = x0 = 4, sy = sx = 8 (assembler.py:180); 256: 16 x 16, 32, 64 (:143)
+ *   primpos [B,K,3] = postex(c);  vcenterdu [B,K,3] = postex(c+(0,1)) - postex(c);  vcenterdv = postex(c+(1,0)) - postex(c)
+ * Forward is bit-identical to the eager expression.  Backward OVERWRITES grad_geo [B,V,3] (fp32 atomics, like the
+ * reference's index_add); any of the three incoming gradients may be NULL (= zero). */
+int mvp_prim_placement_forward(int B, int V, int T, int ny, int nx, int y0, int sy, int x0, int sx, float volradius,
+                               const float *geo, const int *idxim, const float *barim, float *primpos,
+                               float *vcenterdu, float *vcenterdv, void *stream);
+int mvp_prim_placement_backward(int B, int V, int T, int ny, int nx, int y0, int sy, int x0, int sx, float volradius,
+                                const int *idxim, const float *barim, const float *grad_primpos,
+                                const float *grad_vcenterdu, const float *grad_vcenterdv, float *grad_geo,
+                                void *stream);
 
 /* Gradient hygiene of the optimisation loop as two multi-tensor passes.  Replaces, per
  * iteration, the per-parameter eager sequence of /root/reference/ddp-train.py:434-441:

@@ -39,3 +39,19 @@ def scene_rays(oracle, s):
     """Rays of a synthetic scene computed by the oracle (float64)."""
     return oracle.raydirs(s["campos"].numpy(), s["camrot"].numpy(), s["focal"].numpy(), s["princpt"].numpy(),
                           s["pixelcoords"].numpy(), s["volradius"])
+
+
+def make_placement_inputs(nprims, B=None, V=7306, T=1024, seed=77):
+    """Seeded inputs of the primitive-placement tests (shared by tests/golden/gen_placement.py, which feeds them to the
+    reference's own statements): geo [B,V,3] in millimetre-like units, idxim [T,T,3] vertex indices, barim [T,T,3]
+    barycentric weights, volradius, and three weight arrays for a scalar loss."""
+    rng = np.random.default_rng(seed + nprims)
+    B = B or (2 if nprims == 16384 else 3)
+    geo = (rng.normal(size=(B, V, 3)) * 60.0).astype(np.float32)
+    idxim = rng.integers(0, V, size=(T, T, 3), dtype=np.int64)
+    bar = rng.random(size=(T, T, 3)).astype(np.float32) + np.float32(0.05)
+    barim = (bar / bar.sum(-1, keepdims=True)).astype(np.float32)
+    ny, nx = (16, 16) if nprims == 256 else (128, 128)
+    w = (rng.normal(size=(B, nprims, 3)).astype(np.float32), rng.normal(size=(B, ny, nx, 3)).astype(np.float32),
+         rng.normal(size=(B, ny, nx, 3)).astype(np.float32))
+    return geo, idxim, barim, 256.0, w

@@ -1,0 +1,75 @@
+"""Primitive placement on the mesh (barycentric half of row N2; models/decoders/assembler.py:118-122,143-206).
+
+tests/golden/placement_ref.npz = outputs of the reference's own statements (tests/golden/gen_placement.py) on seeded
+inputs that `helpers.make_placement_inputs` regenerates here.
+CPU: the oracle reproduces them (forward bit for bit, gradient to fp32 accumulation accuracy).
+GPU: the HIP kernel through the C ABI reproduces them the same way."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import make_placement_inputs
+from oracle.placement_oracle import placement, placement_backward
+
+REF = np.load(os.path.join(GOLDEN, "placement_ref.npz"))
+
+
+@pytest.mark.parametrize("nprims", [256, 16384])
+def test_oracle_matches_reference_statements(nprims):
+    geo, idxim, barim, volradius, w = make_placement_inputs(nprims)
+    primpos, du, dv = placement(geo, idxim, barim, np.float32(volradius), nprims)
+    tag = "k%d_" % nprims
+    np.testing.assert_array_equal(primpos, REF[tag + "primpos"])
+    np.testing.assert_array_equal(du, REF[tag + "vcenterdu"])
+    np.testing.assert_array_equal(dv, REF[tag + "vcenterdv"])
+    gg = placement_backward(geo.shape, idxim, barim, volradius, nprims, *w)
+    ref = REF[tag + "grad_geo"]
+    assert np.abs(gg - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nprims", [256, 16384])
+def test_hip_matches_reference_statements(nprims):
+    from ava256_amd.placement import prim_placement
+    geo, idxim, barim, volradius, w = make_placement_inputs(nprims)
+    dev = torch.device("cuda", 0)
+    g = torch.from_numpy(geo).to(dev).requires_grad_(True)
+    idx = torch.from_numpy(idxim).to(dev)            # int64, as the reference registers it (assembler.py:63)
+    bar = torch.from_numpy(barim).to(dev)
+    primpos, du, dv = prim_placement(g, idx, bar, volradius, nprims)
+    tag = "k%d_" % nprims
+    assert primpos.shape == REF[tag + "primpos"].shape and du.shape == REF[tag + "vcenterdu"].shape
+    np.testing.assert_array_equal(primpos.detach().cpu().numpy(), REF[tag + "primpos"])   # bit-identical
+    np.testing.assert_array_equal(du.detach().cpu().numpy(), REF[tag + "vcenterdu"])
+    np.testing.assert_array_equal(dv.detach().cpu().numpy(), REF[tag + "vcenterdv"])
+    wt = [torch.from_numpy(x).to(dev) for x in w]
+    ((primpos * wt[0]).sum() + (du * wt[1]).sum() + (dv * wt[2]).sum()).backward()
+    ref = REF[tag + "grad_geo"]
+    assert np.abs(g.grad.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    # a loss that uses only one output: the other incoming gradients are None / zero
+    g.grad = None
+    p2, du2, dv2 = prim_placement(g, idx.to(torch.int32), bar, volradius, nprims)
+    (du2 * wt[1]).sum().backward()
+    want = placement_backward(geo.shape, idxim, barim, volradius, nprims, np.zeros_like(w[0]), w[1], np.zeros_like(w[2]))
+    assert np.abs(g.grad.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_hip_placement_errors():
+    from ava256_amd.placement import prim_placement
+    geo, idxim, barim, volradius, _ = make_placement_inputs(256)
+    dev = torch.device("cuda", 0)
+    g, idx, bar = torch.from_numpy(geo).to(dev), torch.from_numpy(idxim).to(dev), torch.from_numpy(barim).to(dev)
+    with pytest.raises(ValueError):
+        prim_placement(g, idx, bar, volradius, 4096)       # the reference has no u/v centres for it either
+    with pytest.raises(RuntimeError):
+        prim_placement(g.cpu(), idx, bar, volradius, 256)  # no CPU path
+    with pytest.raises(RuntimeError):
+        prim_placement(g.double(), idx, bar, volradius, 256)
+    with pytest.raises(RuntimeError):
+        prim_placement(g, idx[:512], bar[:512], volradius, 256)  # not square
+    with pytest.raises(RuntimeError):
+        prim_placement(g, idx[:512, :512].contiguous(), bar[:512, :512].contiguous(), volradius, 256)  # grid beyond the map
