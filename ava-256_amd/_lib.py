@@ -31,6 +31,9 @@ SIGNATURES = {
 }
 SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
+# N,H,W | rayrgba | rayrgb,rayalpha | stream     and     N,H,W | g_rgb,g_alpha | g_rgba | stream
+SIGNATURES["mvp_rgba_split_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_void_p])
+SIGNATURES["mvp_rgba_split_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_void_p])
 # B,V,T,ny,nx,y0,sy,x0,sx | volradius | geo,idxim,barim | primpos,du,dv | stream
 SIGNATURES["mvp_prim_placement_forward"] = (_c_int, [_c_int] * 9 + [_c_float] + [_c_void_p] * 6 + [_c_void_p])
 # B,V,T,ny,nx,y0,sy,x0,sx | volradius | idxim,barim | g_primpos,g_du,g_dv | grad_geo | stream
@@ -39,7 +42,7 @@ SIGNATURES["mvp_prim_placement_backward"] = (_c_int, [_c_int] * 9 + [_c_float] +
 SIGNATURES["mvp_grads_sanitize_sqnorm"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_void_p])
 # ntensors | grads, numels | sqnorm | max_norm | total_norm | stream
 SIGNATURES["mvp_grads_clip_scale"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 2)
-ABI_VERSION = 5
+ABI_VERSION = 6
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -30,3 +30,58 @@ extern "C" int mvp_device_arch(int device, char *buf, int buflen) {
     buf[buflen - 1] = 0;
     return MVP_OK;
 }
+
+// ---- NHWC -> NCHW split of the march result (row A14 / N1, second half) ------------------------------------------
+// The reference's Raymarcher permutes the [N,H,W,4] march output to NCHW and makes two contiguous copies,
+// rayrgb = rgba[:, :3] and rayalpha = rgba[:, 3:4] (models/raymarchers/mvpraymarcher.py:50-51); autograd then runs the
+// slice / copy backward as several more passes.  One pass each way here: a thread owns one pixel, reads (writes) its
+// 16-byte RGBA and writes (reads) four plane elements -- both sides fully coalesced.  Pure data movement: bit-exact.
+namespace mvp {
+__global__ __launch_bounds__(256) void rgba_split_fwd_kernel(const float4 *__restrict__ rgba, size_t hw, size_t total,
+                                                             float *__restrict__ rgb, float *__restrict__ alpha) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t n = g / hw, p = g - n * hw;
+    const float4 v = rgba[g];
+    float *o = rgb + n * 3 * hw + p;
+    o[0] = v.x, o[hw] = v.y, o[2 * hw] = v.z;
+    alpha[g] = v.w;
+}
+__global__ __launch_bounds__(256) void rgba_split_bwd_kernel(const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
+                                                             size_t hw, size_t total, float4 *__restrict__ g_rgba) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t n = g / hw, p = g - n * hw;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_rgb) {
+        const float *i = g_rgb + n * 3 * hw + p;
+        v.x = i[0], v.y = i[hw], v.z = i[2 * hw];
+    }
+    if (g_alpha) v.w = g_alpha[g];
+    g_rgba[g] = v;
+}
+}  // namespace mvp
+
+extern "C" int mvp_rgba_split_forward(int N, int H, int W, const float *rayrgba, float *rayrgb, float *rayalpha,
+                                      void *stream) {
+    if (N < 0 || H < 0 || W < 0) return MVP_ERR_BADARG;
+    const size_t hw = (size_t)H * W, total = hw * (size_t)N;
+    if (total == 0) return MVP_OK;
+    if (!rayrgba || !rayrgb || !rayalpha || !mvp::aligned16(rayrgba)) return MVP_ERR_BADARG;
+    if ((total + 255) / 256 > 0x7fffffffull) return MVP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(mvp::rgba_split_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(rayrgba), hw, total, rayrgb, rayalpha);
+    return mvp::launch_status();
+}
+
+extern "C" int mvp_rgba_split_backward(int N, int H, int W, const float *grad_rayrgb, const float *grad_rayalpha,
+                                       float *grad_rayrgba, void *stream) {
+    if (N < 0 || H < 0 || W < 0) return MVP_ERR_BADARG;
+    const size_t hw = (size_t)H * W, total = hw * (size_t)N;
+    if (total == 0) return MVP_OK;
+    if (!grad_rayrgba || !mvp::aligned16(grad_rayrgba)) return MVP_ERR_BADARG;
+    if ((total + 255) / 256 > 0x7fffffffull) return MVP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(mvp::rgba_split_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_rayrgb, grad_rayalpha, hw, total, reinterpret_cast<float4 *>(grad_rayrgba));
+    return mvp::launch_status();
+}

@@ -12,6 +12,8 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
+from . import _lib
+from ._tensors import aligned, ptr, require_device_f32, stream_ptr
 from .mvpraymarch import mvpraymarch
 
 # renderoptions are forwarded only when they name a keyword of mvpraymarch (the reference filters with
@@ -20,10 +22,38 @@ _OPTION_NAMES = frozenset(inspect.signature(mvpraymarch).parameters) - {
     "raypos", "raydir", "stepsize", "tminmax", "primtransf", "template", "warp", "rayterm"}
 
 
+class _SplitRGBA(torch.autograd.Function):
+    """[N,H,W,4] -> rgb [N,3,H,W], alpha [N,1,H,W] in one pass each way (mvp_rgba_split_*; mvpraymarcher.py:50-51)."""
+
+    @staticmethod
+    def forward(ctx, rgba):
+        N, H, W = rgba.shape[0], rgba.shape[1], rgba.shape[2]
+        rgb = torch.empty((N, 3, H, W), dtype=torch.float32, device=rgba.device)
+        alpha = torch.empty((N, 1, H, W), dtype=torch.float32, device=rgba.device)
+        with torch.cuda.device(rgba.device):
+            _lib.check(_lib.get_lib().mvp_rgba_split_forward(N, H, W, ptr(rgba), ptr(rgb), ptr(alpha),
+                                                             stream_ptr(rgba.device)), "mvp_rgba_split_forward")
+        ctx.shape = (N, H, W)
+        return rgb, alpha
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha):
+        N, H, W = ctx.shape
+        dev = (g_rgb if g_rgb is not None else g_alpha).device
+        g_rgb = None if g_rgb is None else g_rgb.contiguous()
+        g_alpha = None if g_alpha is None else g_alpha.contiguous()
+        g = torch.empty((N, H, W, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().mvp_rgba_split_backward(N, H, W, ptr(g_rgb), ptr(g_alpha), ptr(g), stream_ptr(dev)),
+                       "mvp_rgba_split_backward")
+        return g
+
+
 def split_rgba_nchw(rayrgba_nhwc: torch.Tensor):
     """[N,H,W,4] -> (rgb [N,3,H,W] contiguous, alpha [N,1,H,W] contiguous, rgba [N,4,H,W] view)."""
-    nchw = rayrgba_nhwc.movedim(3, 1)
-    return nchw[:, 0:3].contiguous(), nchw[:, 3:4].contiguous(), nchw
+    rayrgba_nhwc = aligned(require_device_f32("rayrgba", rayrgba_nhwc))
+    rgb, alpha = _SplitRGBA.apply(rayrgba_nhwc)
+    return rgb, alpha, rayrgba_nhwc.movedim(3, 1)
 
 
 class Raymarcher(nn.Module):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 5
+#define MVP_ABI_VERSION 6
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -120,6 +120,14 @@ int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const 
                                   void *stream);
 int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
                                    float *grad_tex, float *grad_opacity, void *stream);
+
+/* NHWC -> NCHW split of the march result.  Replaces `rayrgba.permute(0,3,1,2)` + `[:, :3].contiguous()` +
+ * `[:, 3:4].contiguous()` of /root/reference/models/raymarchers/mvpraymarcher.py:50-51 (and autograd's slice / copy
+ * backward) by one pass each way.  rayrgba [N,H,W,4] -> rayrgb [N,3,H,W], rayalpha [N,1,H,W]; the backward writes
+ * grad_rayrgba [N,H,W,4] from grad_rayrgb / grad_rayalpha (either may be NULL = zero).  Bit-exact (data movement). */
+int mvp_rgba_split_forward(int N, int H, int W, const float *rayrgba, float *rayrgb, float *rayalpha, void *stream);
+int mvp_rgba_split_backward(int N, int H, int W, const float *grad_rayrgb /*or NULL*/,
+                            const float *grad_rayalpha /*or NULL*/, float *grad_rayrgba, void *stream);
 
 /* Primitive placement on the mesh (the barycentric half of SURVEY.md 8f row N2).  Replaces the eager expression of
  * /root/reference/models/decoders/assembler.py:118-122 -- a 1024 x 1024 x 3 position map per batch element from three

@@ -476,6 +476,32 @@ def test_drop_in_boundary_matches_reference_glue(ops):
     mm.keep_raysat = False
 
 
+def test_rgba_split_is_bit_exact(ops):
+    """Raymarcher's NHWC -> (rgb, alpha) NCHW split (mvpraymarcher.py:50-51) in one pass each way: pure data movement,
+    so forward and backward equal the eager permute / slice / contiguous exactly -- also when only one of the two
+    outputs feeds the loss, and when the third return value (the permuted view) is used as well."""
+    from ava256_amd.raymarcher import split_rgba_nchw
+    torch.manual_seed(3)
+    for shape in [(2, 37, 50, 4), (1, 1, 1, 4), (3, 8, 8, 4)]:
+        x = torch.randn(*shape, device="cuda", requires_grad=True)
+        xr = x.detach().clone().requires_grad_(True)
+        rgb, alpha, view = split_rgba_nchw(x)
+        e = xr.permute(0, 3, 1, 2)
+        ergb, ealpha = e[:, :3].contiguous(), e[:, 3:4].contiguous()
+        assert rgb.is_contiguous() and alpha.is_contiguous() and view.shape == e.shape
+        assert torch.equal(rgb, ergb) and torch.equal(alpha, ealpha) and torch.equal(view, e)
+        w1, w2, w3 = torch.randn_like(rgb), torch.randn_like(alpha), torch.randn_like(view)
+        ((rgb * w1).sum() + (alpha * w2).sum() + (view * w3).sum()).backward()
+        ((ergb * w1).sum() + (ealpha * w2).sum() + (e * w3).sum()).backward()
+        assert torch.equal(x.grad, xr.grad)
+        x.grad = None
+        xr.grad = None
+        rgb, alpha, _ = split_rgba_nchw(x)
+        (rgb * w1).sum().backward()                      # alpha unused: its incoming gradient is None
+        (xr.permute(0, 3, 1, 2)[:, :3].contiguous() * w1).sum().backward()
+        assert torch.equal(x.grad, xr.grad)
+
+
 def test_operator_errors(ops):
     """Error behaviour at the boundary: CPU tensors, wrong dtype, non-contiguous input, unsupported options."""
     from ava256_amd.scene import make_scene
