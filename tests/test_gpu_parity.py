@@ -206,6 +206,54 @@ def test_non_cubic_slabs_and_general_fade(ops, oracle64, shape, fadescale, fadee
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), str(shape))
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MVP_FUZZ_SEEDS", "10")))))  # more with MVP_FUZZ_SEEDS=n
+def test_randomized_configurations(ops, oracle64, seed):
+    """Seeded random draws over image size (ragged packets), primitive count (non powers of two, tiny), slab shape,
+    opacity (none to most rays saturating), box size, step size and fade parameters; forward and all gradients against
+    the float64 oracle with the standing tolerances, backward owner chosen at random as well."""
+    from ava256_amd.scene import make_scene
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(1, 4))
+    H, W = int(rng.integers(9, 71)), int(rng.integers(9, 71))
+    K = int(rng.choice([1, 2, 3, 7, 8, 33, 64, 100, 257, 512, 700]))
+    shape = tuple(int(x) for x in rng.integers(2, 10, size=3)) if rng.random() < 0.5 else (8, 8, 8)
+    again = float(rng.choice([0.5, 2.0, 8.0, 30.0]))
+    fadescale, fadeexp = (8.0, 8.0) if rng.random() < 0.5 else (float(rng.uniform(3, 9)), float(rng.uniform(2.5, 9)))
+    mode = str(rng.choice(BACKWARD_MODES))
+    s = make_scene(N, H, W, K, device="cpu", seed=50 + seed, alpha_gain=1.0, slab=4)
+    s["primscale"] = s["primscale"] * float(rng.uniform(0.35, 1.0) if K < 100 else rng.uniform(0.7, 1.2))
+    stepsize = float(s["stepsize"]) * float(rng.choice([0.5, 1.0, 2.0]))
+    TD, TH, TW = shape
+    tpl = np.concatenate([np.maximum(100 + 25 * rng.normal(size=(N, K, TD, TH, TW, 3)), 0),
+                          again * np.exp(0.1 * rng.normal(size=(N, K, TD, TH, TW, 1)))], axis=-1)
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, stepsize, tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), tpl)
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, fadescale=fadescale, fadeexp=fadeexp)
+    if st["rays_hit"] == 0 or st["list_overflow"] > 0:
+        pytest.skip("degenerate draw")
+    gout = rng.normal(size=ref_rgba.shape)
+    fragile = {}
+
+    def masked_gout(hip_raysat):
+        diff = np.abs(hip_raysat - ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(ref_sat).max())
+        fragile["mask"] = diff
+        g = gout.copy()
+        g[diff] = 0.0
+        return g
+
+    rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=masked_gout, mode=mode)
+    fr = fragile["mask"]
+    cfg = "seed %d: N%d %dx%d K%d slab%s gain%g fade(%g,%g) dt%g mode %s" % (seed, N, H, W, K, shape, again, fadescale,
+                                                                          fadeexp, stepsize, mode)
+    assert fr.sum() <= max(3, 0.01 * fr.size), (cfg, fr.sum())
+    g2 = gout.copy()
+    g2[fr] = 0.0
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, g2, fadescale=fadescale, fadeexp=fadeexp)
+    err = np.abs(rgba - ref_rgba).max(-1)
+    assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0, (cfg, err[~fr].max())
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), cfg)
+
+
 @pytest.mark.parametrize("name", ["march_warp_k8_m8", "march_warp_k8_m8_sat"])
 def test_warp_sampler_matches_reference_golden(ops, name):
     """algo 1 (PrimSamplerTW<true>): fixtures from the reference's gradcheck(dowarp=True) dense loop (float64)."""
