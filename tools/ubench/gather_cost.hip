@@ -1,7 +1,11 @@
 // Microbenchmark: vector-memory gather cost (global_load_dwordx4, L1/L2-resident data) vs. number/arrangement of
-// active lanes on gfx950.  Build: hipcc --offload-arch=gfx950 -O3 gather_cost.hip -o gather_cost
+// active lanes on gfx950.  Measured on MI355X, cycles per wave instruction per CU:
+//   lanes              64     32     16      8      4      1
+//   L1-missing (512K)  143    71     35     20.6   20.9   19.2     (2.24 cycles per lane, floor 20)
+//   L1-resident (16K)  41     22-29  18-23  20.0   20.9   19.7     (a full wave costs 2x the floor)  Build: hipcc --offload-arch=gfx950 -O3 gather_cost.hip -o gather_cost
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 __global__ __launch_bounds__(256) void k(const float4 *__restrict__ data, int nvox, unsigned long long mask, int iters,
@@ -23,8 +27,9 @@ __global__ __launch_bounds__(256) void k(const float4 *__restrict__ data, int nv
     if (acc.x + acc.y + acc.z + acc.w == -1.f) out[0] = acc.x;
 }
 
-int main() {
-    const int nvox = 512 * 64;  // 64 slabs of 8 KB = 512 KB: L2-resident, mostly L1-missing like the real kernel
+int main(int argc, char **argv) {
+    // argv[1] = number of voxels: default 512*64 (64 slabs of 8 KB = 512 KB: L2-resident, L1-missing); 1024 (16 KB) = L1-resident
+    const int nvox = argc > 1 ? atoi(argv[1]) : 512 * 64;
     float4 *d; float *o;
     hipMalloc(&d, nvox * 16); hipMalloc(&o, 4);
     hipMemset(d, 0, nvox * 16);
