@@ -524,6 +524,39 @@ def test_drop_in_boundary_matches_reference_glue(ops):
     mm.keep_raysat = False
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_upstream_gradient(ops, oracle64, bad):
+    """A NaN / Inf in grad_rayrgba (the training loop zeroes such gradients AFTER backward, ddp-train.py:436-439): the
+    fixed-point path cannot bound its sums, so every primitive is handed to the ray-centric kernel, whose fp32 atomics
+    propagate the value exactly where the reference's would -- NaN in the gradients of everything the poisoned ray
+    touches, finite and correct elsewhere."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(1, 32, 32, 64, device="cpu", seed=4, alpha_gain=0.02, slab=8)  # thin: no ray saturates
+    s["primscale"] = s["primscale"] * 0.6
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(),
+         s["template"].numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a)
+    hit = np.argwhere(ref_rgba[0, :, :, 3] > 0)
+    assert len(hit) > 10 and st["rays_saturated"] == 0
+    rng = np.random.default_rng(8)
+    gout = rng.normal(size=ref_rgba.shape)
+    y, x = hit[len(hit) // 2]
+    gout[0, y, x, 1] = bad
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=gout, mode="prim")
+    with np.errstate(invalid="ignore", over="ignore"):
+        rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, gout)
+    for k, ref in (("template", rgt), ("primpos", rgp), ("primrot", rgr), ("primscale", rgs)):
+        got = grads[k]
+        badmask = ~np.isfinite(ref)
+        assert badmask.any() and not badmask.all(), k
+        assert (~np.isfinite(got[badmask])).all(), k                # poisoned where the reference semantics poison
+        ok = ~badmask
+        assert np.isfinite(got[ok]).all(), k
+        tol = (1e-3 if k == "template" else 3e-2) * np.abs(ref[ok]).max()
+        assert np.abs(got[ok] - ref[ok]).max() <= tol, k
+
+
 def test_rgba_split_is_bit_exact(ops):
     """Raymarcher's NHWC -> (rgb, alpha) NCHW split (mvpraymarcher.py:50-51) in one pass each way: pure data movement,
     so forward and backward equal the eager permute / slice / contiguous exactly -- also when only one of the two
