@@ -1258,10 +1258,13 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                 tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
             }
         }
-        for (int v = tid; v < 4 * Vp; v += kPrimBlock) {
-            s_hi[v] = 0;
-            s_lo[v] = 0u;
-            s_gf[v] = 0.f;
+        // hi and lo are adjacent (8 * Vp words from a 16-byte aligned base): 16-byte stores.  The float drain target is
+        // NOT cleared here: it is written (not added to) by the first drain and ignored when there was none.
+        {
+            float4 *z4 = reinterpret_cast<float4 *>(s_hi);
+            const int nz4 = (8 * Vp) >> 2;
+            for (int v = tid; v < nz4; v += kPrimBlock) z4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int v = (nz4 << 2) + tid; v < 8 * Vp; v += kPrimBlock) s_hi[v] = 0;
         }
         tmax = wave_max(tmax);
         if (lane == 0) s_red[wave] = tmax;
@@ -1312,6 +1315,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
 #endif
     if (tid == 0) s_qn[2] = 0u;
     uint32_t pending = 0u;  // samples accumulated into the integer arrays since the last drain (workgroup-uniform)
+    bool drained = false;   // the float drain target holds data (workgroup-uniform)
     for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
         if (tid < kLenBuckets) s_bucket[tid] = 0u;
         if (tid == 0) s_qn[1] = 0u;
@@ -1429,10 +1433,12 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             asm volatile("; drain addresses are made here" : "+v"(td));
             for (int v = td; v < 4 * Vp; v += kPrimBlock) {
                 const float inv = v < 3 * Vp ? i_rgb : i_a;
-                s_gf[v] += fix_value(s_hi[v], s_lo[v]) * inv;
+                const float add = fix_value(s_hi[v], s_lo[v]) * inv;
+                s_gf[v] = drained ? s_gf[v] + add : add;
                 s_hi[v] = 0;
                 s_lo[v] = 0u;
             }
+            drained = true;
             pending = 0u;
             __syncthreads();
         }
@@ -1699,10 +1705,14 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
-            g.x = s_gf[gv] + fix_value(s_hi[gv], s_lo[gv]) * i_rgb;
-            g.y = s_gf[Vp + gv] + fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
-            g.z = s_gf[2 * Vp + gv] + fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
-            g.w = s_gf[3 * Vp + gv] + fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
+            g.x = fix_value(s_hi[gv], s_lo[gv]) * i_rgb;
+            g.y = fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
+            g.z = fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
+            g.w = fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
+            if (drained) {  // (workgroup-uniform) earlier drains, in the order they happened
+                g.x = s_gf[gv] + g.x, g.y = s_gf[Vp + gv] + g.y;
+                g.z = s_gf[2 * Vp + gv] + g.z, g.w = s_gf[3 * Vp + gv] + g.w;
+            }
             gT4l[v] = g;
         }
     }
