@@ -32,15 +32,13 @@ __device__ __forceinline__ float rgb_denorm(float v) {
 __global__ __launch_bounds__(256) void assemble_fwd_kernel(int N, int nh, int B, const float *__restrict__ tex,
                                                            const float *__restrict__ opac,
                                                            float *__restrict__ tplate) {
+    // grid = (x chunks of one image row, image rows, N * B): no 64-bit index arithmetic (three 64-bit div/mod per
+    // 128 bytes moved made the first version of these kernels instruction-bound)
     const int S = nh * B, S4 = S >> 2;
-    const long long total = (long long)N * B * S * S4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int X4 = (int)(i % S4);
-        long long r = i / S4;
-        const int R = (int)(r % S);
-        r /= S;
-        const int z = (int)(r % B), n = (int)(r / B);
+    const int X4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (X4 < S4) {
+        const int R = blockIdx.y;
+        const int n = (int)blockIdx.z / B, z = (int)blockIdx.z - n * B;
         const int X = X4 << 2;
         const size_t plane = (size_t)S * S, rowoff = (size_t)R * S + X;
         const float *tp = tex + ((size_t)n * 3 * B + (size_t)z * 3) * plane + rowoff;
@@ -64,15 +62,13 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(int N, int nh, int B,
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(int N, int nh, int B, const float *__restrict__ tplate,
                                                            const float *__restrict__ gtpl,
                                                            float *__restrict__ gtex, float *__restrict__ gopac) {
+    // grid = (x chunks of one image row, image rows, N * B): no 64-bit index arithmetic (three 64-bit div/mod per
+    // 128 bytes moved made the first version of these kernels instruction-bound)
     const int S = nh * B, S4 = S >> 2;
-    const long long total = (long long)N * B * S * S4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int X4 = (int)(i % S4);
-        long long r = i / S4;
-        const int R = (int)(r % S);
-        r /= S;
-        const int z = (int)(r % B), n = (int)(r / B);
+    const int X4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (X4 < S4) {
+        const int R = blockIdx.y;
+        const int n = (int)blockIdx.z / B, z = (int)blockIdx.z - n * B;
         const int X = X4 << 2;
         const size_t plane = (size_t)S * S, rowoff = (size_t)R * S + X;
         const int hy = R / B, y = R - hy * B, wx = X / B, x = X - wx * B;
@@ -112,10 +108,10 @@ extern "C" int mvp_template_assemble_forward(int N, int nh, int B, const float *
     const long long S = (long long)nh * B, total = (long long)N * B * S * (S / 4);
     if (total == 0) return MVP_OK;
     if (!tex || !opacity || !tplate || !aligned16(tex) || !aligned16(opacity) || !aligned16(tplate)) return MVP_ERR_BADARG;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(assemble_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, N, nh, B, tex,
-                       opacity, tplate);
+    if ((long long)N * B > 65535 || S > 65535) return MVP_ERR_UNSUPPORTED;
+    const int bx = S / 4 >= 256 ? 256 : (int)(S / 4);
+    const dim3 grid((unsigned)((S / 4 + bx - 1) / bx), (unsigned)S, (unsigned)(N * B));
+    hipLaunchKernelGGL(assemble_fwd_kernel, grid, dim3(bx), 0, (hipStream_t)stream, N, nh, B, tex, opacity, tplate);
     return launch_status();
 }
 
@@ -129,9 +125,10 @@ extern "C" int mvp_template_assemble_backward(int N, int nh, int B, const float 
     if (!tplate || !grad_tplate || !grad_tex || !grad_opacity || !aligned16(tplate) || !aligned16(grad_tplate) ||
         !aligned16(grad_tex) || !aligned16(grad_opacity))
         return MVP_ERR_BADARG;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, N, nh, B, tplate,
-                       grad_tplate, grad_tex, grad_opacity);
+    if ((long long)N * B > 65535 || S > 65535) return MVP_ERR_UNSUPPORTED;
+    const int bx = S / 4 >= 256 ? 256 : (int)(S / 4);
+    const dim3 grid((unsigned)((S / 4 + bx - 1) / bx), (unsigned)S, (unsigned)(N * B));
+    hipLaunchKernelGGL(assemble_bwd_kernel, grid, dim3(bx), 0, (hipStream_t)stream, N, nh, B, tplate, grad_tplate,
+                       grad_tex, grad_opacity);
     return launch_status();
 }
