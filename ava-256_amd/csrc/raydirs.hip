@@ -28,9 +28,15 @@ __global__ __launch_bounds__(kRdBlock) void raydirs_kernel(int N, int H, int W, 
         const bool valid = r < total;
         f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
         if (valid) {
-            const int n = (int)(r / HW);
-            const int hw = (int)(r - (long long)n * HW);
-            const int h = hw / W, w = hw - h * W;
+            int n, hw;
+            if (total < 0x7fffffffll) {  // (uniform) 32-bit division: a 64-bit one is ~80 VALU instructions per wave
+                n = (int)((unsigned)r / (unsigned)HW);
+                hw = (int)((unsigned)r - (unsigned)n * (unsigned)HW);
+            } else {
+                n = (int)(r / HW);
+                hw = (int)(r - (long long)n * HW);
+            }
+            const int h = (int)((unsigned)hw / (unsigned)W), w = hw - h * W;
             o = ld3(campos + n * 3);
             o = mk3(o.x / volradius, o.y / volradius, o.z / volradius);
             const float *R = camrot + n * 9;
