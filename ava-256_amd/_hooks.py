@@ -9,6 +9,7 @@ force_ray_centric_backward = False  # tests: skip the forward->backward hand-off
 primlist_cap_override = None        # tests: force a (small) per-primitive list capacity
 keep_raysat = False                 # tests: keep the last forward's raysat tensor in `last_raysat`
 last_raysat = None
+last_pl_count = None                # ... and its forward->backward hand-off counters ([N*K] counts, then flags, bounds)
 
 
 def set_diag_buffer(t):

@@ -117,6 +117,7 @@ class MVPRaymarch(Function):
 
         if _hooks.keep_raysat:
             _hooks.last_raysat = raysat
+            _hooks.last_pl_count = pl_count
         ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
                               pl_count, pl_list, warp)
         ctx.pl_cap = pl_cap

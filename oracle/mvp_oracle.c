@@ -262,6 +262,19 @@ static void tri_fetch(const real *G, int C, const tri_t *tr, real *out) {
             for (int ch = 0; ch < C; ++ch) out[ch] += G[(size_t)tr->idx[c] * C + ch] * tr->w[c];
 }
 
+/* Optional per-ray diagnostics of the forward march (tests only; all NULL by default, set through
+ * mvpo_set_ray_diagnostics and valid for the next calls until reset):
+ *   margin[r]   = min over the evaluated samples of |alpha_after_sample - 1|  (INFINITY when the ray takes no sample):
+ *                 how close the saturation decision `newalpha >= 1` (primaccum.h:71) came to flipping;
+ *   hitcount[r] = primitives listed for the ray (utils.h:757-781);   nsamples[r] = samples evaluated. */
+static real *g_margin = NULL;
+static int *g_hitcount = NULL, *g_nsamples = NULL;
+void mvpo_set_ray_diagnostics(real *margin, int *hitcount, int *nsamples) {
+    g_margin = margin;
+    g_hitcount = hitcount;
+    g_nsamples = nsamples;
+}
+
 /* warp may be NULL (algo 0).  With a warp field [N,K,WD,WH,WW,3] the template is sampled at y1 = warp(y0)
  * (PrimSamplerTW<true>, primsampler.h:53-58); the fade still uses y0. */
 int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const real *raydir, real stepsize,
@@ -291,7 +304,8 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
             int nh = traverse(K, o, d, A, pp, pr, ps, maxhitboxes, hits, &rtmin, &rtmax, &ovf);
             st3 += ovf;
             real rgba[4] = {0, 0, 0, 0}, sat3[3] = {-1, -1, -1};
-            int sat = 0;
+            int sat = 0, myns = 0;
+            real margin = INFINITY;
             rtmin = rmax(rtmin, tmn); /* subset_kernel.h:63-64 */
             rtmax = rmin(rtmax, tmx);
             if (nh > 0 && rtmin < INFINITY) {
@@ -326,6 +340,8 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
                             /* primaccum.h:63-79 */
                             real newalpha = rgba[3] + v[3] * stepsize;
                             real contrib = rmin(newalpha, (real)1) - rgba[3];
+                            margin = rmin(margin, R_ABS(newalpha - (real)1));
+                            ++myns;
                             rgba[0] += v[0] * contrib;
                             rgba[1] += v[1] * contrib;
                             rgba[2] += v[2] * contrib;
@@ -345,6 +361,9 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
                 }
             }
             st5 += sat;
+            if (g_margin) g_margin[r] = margin;
+            if (g_hitcount) g_hitcount[r] = nh;
+            if (g_nsamples) g_nsamples[r] = myns;
             for (int j = 0; j < 4; ++j) rayrgba[r * 4 + j] = rgba[j];
             if (raysat)
                 for (int j = 0; j < 3; ++j) raysat[r * 3 + j] = sat3[j];

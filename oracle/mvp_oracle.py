@@ -71,7 +71,7 @@ class Oracle:
         return out
 
     def march_forward(self, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template,
-                      fadescale=8.0, fadeexp=8.0, maxhitboxes=512, want_raysat=True, nodeaabb=None, warp=None):
+                      fadescale=8.0, fadeexp=8.0, maxhitboxes=512, want_raysat=True, nodeaabb=None, warp=None, ray_diagnostics=False):
         raypos, raydir, tminmax, primpos, primrot, primscale, template = map(
             self._a, (raypos, raydir, tminmax, primpos, primrot, primscale, template))
         N, H, W = raypos.shape[:3]
@@ -89,14 +89,25 @@ class Oracle:
             warp = self._a(warp)
             WD, WH, WW = warp.shape[2:5]
             assert warp.shape[5] == 3
+        margin = hitcount = nsamples = None
+        if ray_diagnostics:
+            margin = np.empty((N, H, W), self.dtype)
+            hitcount = np.empty((N, H, W), np.int32)
+            nsamples = np.empty((N, H, W), np.int32)
+            self.lib.mvpo_set_ray_diagnostics(self._p(margin), self._p(hitcount), self._p(nsamples))
         rc = self.lib.mvpo_march_forward(
             N, H, W, K, self._p(raypos), self._p(raydir), self._creal(stepsize), self._p(tminmax),
             self._p(nodeaabb), self._p(primpos), self._p(primrot), self._p(primscale), TD, TH, TW,
             self._p(template), WD, WH, WW, self._p(warp), self._p(rgba), self._p(raysat), self._creal(fadescale),
             self._creal(fadeexp), int(maxhitboxes), stats.ctypes.data_as(ctypes.c_void_p))
+        if ray_diagnostics:
+            self.lib.mvpo_set_ray_diagnostics(None, None, None)
         assert rc == 0
         names = ["rays_hit", "list_len_sum", "samples", "list_overflow", "steps", "rays_saturated"]
-        return rgba, raysat, dict(zip(names, stats[:6].tolist()))
+        st = dict(zip(names, stats[:6].tolist()))
+        if ray_diagnostics:  # per-ray: saturation margin min|alpha_after - 1|, listed primitives, evaluated samples
+            st.update(margin=margin, hitcount=hitcount, nsamples=nsamples)
+        return rgba, raysat, st
 
     def march_backward(self, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, raysat,
                        grad_rayrgba, fadescale=8.0, fadeexp=8.0, maxhitboxes=512, nodeaabb=None, warp=None):

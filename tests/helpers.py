@@ -35,6 +35,36 @@ def load_krt_400940():
     return campos, camrot, focal, princpt
 
 
+SAT_BAND = 1e-4  # a ray may disagree with the float64 oracle on its saturating sample only inside this band
+
+
+class FragileRays:
+    """Saturation (primaccum.h:71, `newalpha >= 1`) is a discontinuity of the gradient: a ray whose running alpha
+    passes 1.0 by less than fp32 round-off may saturate at a different sample than in float64.  Such rays get zero
+    upstream gradient on both sides -- but ONLY when the ORACLE says they are borderline: `margin` is the float64
+    oracle's own min over the ray's samples of |alpha_after_sample - 1| (Oracle.march_forward(ray_diagnostics=True)).
+    A ray whose kernel `raysat` disagrees with the oracle's although its margin is >= SAT_BAND fails the test."""
+
+    def __init__(self, ref_sat, margin, gout, max_frac=0.005, min_allowed=2):
+        self.ref_sat, self.margin, self.gout = ref_sat, margin, gout
+        self.max_frac, self.min_allowed = max_frac, min_allowed
+        self.mask = None
+
+    def __call__(self, hip_raysat):
+        diff = np.abs(hip_raysat - self.ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(self.ref_sat).max())
+        unjustified = diff & ~(self.margin < SAT_BAND)
+        assert unjustified.sum() == 0, ("rays saturate differently from the oracle outside the %g band" % SAT_BAND,
+                                        int(unjustified.sum()), float(self.margin[unjustified].min()))
+        assert diff.sum() <= max(self.min_allowed, self.max_frac * diff.size), int(diff.sum())
+        self.mask = diff
+        return self.masked()
+
+    def masked(self):
+        g = self.gout.copy()
+        g[self.mask] = 0.0
+        return g
+
+
 def scene_rays(oracle, s):
     """Rays of a synthetic scene computed by the oracle (float64)."""
     return oracle.raydirs(s["campos"].numpy(), s["camrot"].numpy(), s["focal"].numpy(), s["princpt"].numpy(),

@@ -1,7 +1,8 @@
 """Parity at the BASELINE.json configuration sizes.
 
-* C1 (4 cams, 128x128, K=512) and a one-camera slice of C3/C5 (512x512, K=16384) are small enough for the float64
-  oracle: full forward + backward comparison.
+* C1 (4 cams, 128x128, K=512), one camera of C2 (512x512, K=4096, at alpha gain 1 and 20), a one-camera slice of C3/C5
+  (512x512, K=16384) and one camera of C4 (1024x1024, K=8192) go through the float64 oracle: forward + all gradients.
+* C3/C5 and C4 at their full per-GPU batch (N=4) are checked through properties + kernel diagnostics.
 * C2 (80 cams, 512x512, K=4096 -- the bench workload) is checked through size-independent properties:
     - tile independence: rendering a sub-rectangle of pixels gives bit-identical rays (packets differ, rays do not);
     - linearity: scaling the rgb channels of every slab by c scales rgb by c and leaves alpha untouched;
@@ -13,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import cosine, npf, scene_rays
+from helpers import FragileRays, cosine, npf, scene_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -31,19 +32,30 @@ def _render(ops, s, sl=slice(None), grad=False, gout=None):
     return rgba, None
 
 
-@pytest.mark.parametrize("cfg", [("C1", 4, 128, 128, 512, 1.0), ("C1sat", 4, 128, 128, 512, 30.0),
-                                 ("C3slice", 1, 512, 512, 16384, 6.0)], ids=lambda c: c[0])
-def test_config_sizes_against_oracle(cfg, oracle64):
+ORACLE_CONFIGS = [
+    # name, N, H, W, K, alpha_gain -- every BASELINE.json configuration is represented at its real image size and K;
+    # the camera count is cut to what the float64 oracle finishes in seconds on the GPU box's host cores
+    ("C1", 4, 128, 128, 512, 1.0), ("C1sat", 4, 128, 128, 512, 30.0),
+    ("C2cam", 1, 512, 512, 4096, 1.0), ("C2cam_a20", 1, 512, 512, 4096, 20.0),      # one camera of the bench workload
+    ("C3slice", 1, 512, 512, 16384, 6.0),
+    ("C4cam", 1, 1024, 1024, 8192, 1.0), ("C4cam_a12", 1, 1024, 1024, 8192, 12.0),  # 16384 packets/image, K between the tuned sizes
+]
+
+
+@pytest.mark.parametrize("cfg", ORACLE_CONFIGS, ids=lambda c: c[0])
+def test_config_sizes_against_oracle(cfg, oracle64, oracle32):
     import ava256_amd as ops
+    from ava256_amd import _hooks
     from ava256_amd.scene import make_scene
     name, N, H, W, K, again = cfg
     s = make_scene(N, H, W, K, device="cpu", seed=1112, alpha_gain=again)
     rp, rd, tm = scene_rays(oracle64, s)
     a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
-    ref, ref_sat, st = oracle64.march_forward(*a)
+    ref, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
     assert st["list_overflow"] == 0
     d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in s.items()}
-    from ava256_amd import _hooks
+    diag = torch.zeros(8, dtype=torch.int32, device="cuda")
+    _hooks.set_diag_buffer(diag)
     _hooks.keep_raysat = True
     rng = np.random.default_rng(1)
     gout = rng.normal(size=ref.shape)
@@ -51,26 +63,128 @@ def test_config_sizes_against_oracle(cfg, oracle64):
     t = {k: d[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
     rgba = ops.mvpraymarch(rp_d, rd_d, d["stepsize"], tm_d, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
     hip_sat = npf(_hooks.last_raysat)
+    handoff = _hooks.last_pl_count
     _hooks.keep_raysat = False
-    _hooks.last_raysat = None
-    fragile = np.abs(hip_sat - ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(ref_sat).max())
-    assert fragile.sum() <= 0.005 * fragile.size
-    gout[fragile] = 0.0
+    _hooks.last_raysat = _hooks.last_pl_count = None
+    fragile = FragileRays(ref_sat, st["margin"], gout)   # only rays the ORACLE calls borderline may be masked
+    gout = fragile(hip_sat)
+    fr = fragile.mask
     rgba.backward(torch.as_tensor(gout, dtype=torch.float32, device="cuda"))
+    dg = _hooks.read_diag()
+    _hooks.set_diag_buffer(None)
+    print(name, "diag", dg, "fragile", int(fr.sum()), "saturated rays", st["rays_saturated"], "of", st["rays_hit"])
+    assert dg["list_overflow"] == 0 and dg["frontier_overflow"] <= 0.02 * max(1, dg["packets_hit"]), dg
+    # no primitive may fall off the primitive-centric path at a BASELINE configuration (capacity heuristic check)
+    flags = int(handoff[N * K].item())   # read after the backward: bit 0 = some primitive left the primitive-centric path
+    assert flags == 0, flags
     out = npf(rgba)
     scale = max(1.0, np.abs(ref).max())
-    assert (np.abs(out - ref).max(-1)[~fragile] > 2e-4 * scale).sum() == 0
+    assert (np.abs(out - ref).max(-1)[~fr] > 2e-4 * scale).sum() == 0
     gp, gr, gs, gt = oracle64.march_backward(*a, ref_sat, gout)
     assert np.abs(npf(t["template"].grad) - gt).max() <= 1e-3 * np.abs(gt).max()
-    # Pose gradients on white-noise slabs cancel heavily.  Calibration (CPU, this scene family): the float32 build of
-    # the oracle -- the reference's algorithm in the kernels' arithmetic type -- sits at max-abs 5.6e-2 .. 8.8e-2 of
-    # max|g|, norm-wise 3.7e-3 .. 6.8e-3, cosine 0.99998 against float64 on the C3 slice (K = 16384).  The HIP
-    # kernels are held to: cosine >= 0.9999, norm-wise 1e-2, max-abs 1e-1.
-    for mine, refg in ((t["primpos"].grad, gp), (t["primrot"].grad, gr), (t["primscale"].grad, gs)):
+    # Pose gradients on white-noise slabs cancel heavily, so the honest yardstick is the SAME algorithm in the SAME
+    # arithmetic type: the float32 build of the oracle (the reference's per-ray loop in fp32, incremental t) against
+    # float64.  Absolute bounds: cosine >= 0.9999, norm-wise 1e-2, max-abs 1e-1; relative bound: the HIP kernels may
+    # not be worse than 2x the fp32 oracle's own norm-wise error (+1e-4).
+    ref32, sat32, _ = oracle32.march_forward(*a)
+    g32 = oracle32.march_backward(*a, sat32, gout)
+    for mine, refg, o32, nm in ((t["primpos"].grad, gp, g32[0], "pos"), (t["primrot"].grad, gr, g32[1], "rot"),
+                                (t["primscale"].grad, gs, g32[2], "scale")):
         m = npf(mine)
+        e_hip = np.linalg.norm(m - refg) / np.linalg.norm(refg)
+        e_o32 = np.linalg.norm(o32.astype(np.float64) - refg) / np.linalg.norm(refg)
+        print("   %s grad_%s: HIP norm-wise %.2e, fp32 oracle %.2e, HIP vs fp32 oracle %.2e" % (
+            name, nm, e_hip, e_o32, np.linalg.norm(m - o32) / np.linalg.norm(refg)))
         assert cosine(m, refg) >= 0.9999
-        assert np.linalg.norm(m - refg) <= 1e-2 * np.linalg.norm(refg)
+        assert e_hip <= 1e-2
+        assert e_hip <= 2.0 * e_o32 + 1e-4, (nm, e_hip, e_o32)
         assert np.abs(m - refg).max() <= 1e-1 * np.abs(refg).max()
+
+
+@pytest.mark.parametrize("cfg", [("C1smooth", 4, 128, 128, 512, 6.0), ("C3smooth", 1, 512, 512, 16384, 6.0)],
+                         ids=lambda c: c[0])
+def test_smooth_templates_tight_pose_gradients(cfg, oracle64):
+    """Smooth slabs (low-order polynomial in the box coordinates instead of white noise) remove the cancellation that
+    forces the loose pose-gradient bounds above: here the kernels are held to 1e-3 norm-wise and 5e-3 max-abs against
+    float64 ("<= 1e-3 on smooth-template fixtures")."""
+    import ava256_amd as ops
+    from ava256_amd import _hooks
+    from ava256_amd.scene import make_scene
+    name, N, H, W, K, again = cfg
+    s = make_scene(N, H, W, K, device="cpu", seed=77, alpha_gain=1.0)
+    g = torch.Generator().manual_seed(3)
+    lin = torch.linspace(-1.0, 1.0, 8)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    c = torch.randn(N, K, 4, 4, generator=g)
+    poly = (c[..., 0, None, None, None] + c[..., 1, None, None, None] * xx + c[..., 2, None, None, None] * yy +
+            c[..., 3, None, None, None] * zz)                                  # [N,K,4,8,8,8]
+    tpl = torch.empty(N, K, 8, 8, 8, 4)
+    tpl[..., :3] = (100 + 30 * poly[:, :, :3]).permute(0, 1, 3, 4, 5, 2).clamp(min=0)
+    tpl[..., 3] = again * torch.exp(0.3 * poly[:, :, 3])
+    s["template"] = tpl.contiguous()
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
+    ref, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in s.items()}
+    _hooks.keep_raysat = True
+    gout = np.random.default_rng(5).normal(size=ref.shape)
+    rp_d, rd_d, tm_d = ops.compute_raydirs(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"])
+    t = {k: d[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
+    rgba = ops.mvpraymarch(rp_d, rd_d, d["stepsize"], tm_d, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
+    fragile = FragileRays(ref_sat, st["margin"], gout)
+    gout = fragile(npf(_hooks.last_raysat))
+    _hooks.keep_raysat = False
+    _hooks.last_raysat = None
+    rgba.backward(torch.as_tensor(gout, dtype=torch.float32, device="cuda"))
+    assert (np.abs(npf(rgba) - ref).max(-1)[~fragile.mask] > 2e-4 * max(1.0, np.abs(ref).max())).sum() == 0
+    gp, gr, gs, gt = oracle64.march_backward(*a, ref_sat, gout)
+    assert np.abs(npf(t["template"].grad) - gt).max() <= 1e-3 * np.abs(gt).max()
+    for mine, refg, nm in ((t["primpos"].grad, gp, "pos"), (t["primrot"].grad, gr, "rot"), (t["primscale"].grad, gs, "scale")):
+        m = npf(mine)
+        e = np.linalg.norm(m - refg) / np.linalg.norm(refg)
+        print("   %s grad_%s norm-wise %.2e max-abs %.2e" % (name, nm, e, np.abs(m - refg).max() / np.abs(refg).max()))
+        assert e <= 1e-3, (nm, e)
+        assert np.abs(m - refg).max() <= 5e-3 * np.abs(refg).max(), nm
+
+
+@pytest.mark.parametrize("cfg", [("C3", 4, 512, 512, 16384, 6.0), ("C4", 4, 1024, 1024, 8192, 12.0)], ids=lambda c: c[0])
+def test_full_batch_properties(cfg):
+    """C3/C5 and C4 at their FULL per-GPU batch (N = 4): diagnostics (no list overflow, frontier overflow rare, no
+    primitive pushed to the ray-centric fallback), image 0 bit-identical to the same camera rendered alone, Euler
+    homogeneity of the slab gradient, bit-reproducible slab gradient, and the two backward owners agreeing."""
+    import ava256_amd as ops
+    from ava256_amd import _hooks
+    from ava256_amd.scene import make_scene
+    name, N, H, W, K, again = cfg
+    s = make_scene(N, H, W, K, device="cuda", seed=1112, alpha_gain=again)
+    diag = torch.zeros(8, dtype=torch.int32, device="cuda")
+    _hooks.set_diag_buffer(diag)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    gout = torch.randn(N, H, W, 4, device="cuda", generator=g)
+    rgba, grads = _render(ops, s, grad=True, gout=gout)
+    d = _hooks.read_diag()
+    _hooks.set_diag_buffer(None)
+    print(name, "diag", d)
+    assert d["list_overflow"] == 0 and d["frontier_overflow"] <= 0.02 * max(1, d["packets_hit"]), d
+    assert d["max_list"] <= 512
+    for v in grads.values():
+        assert torch.isfinite(v).all()
+    one, _ = _render(ops, s, slice(0, 1))
+    assert torch.equal(one[0], rgba[0])
+    lhs = (s["template"][..., :3].double() * grads["template"][..., :3].double()).sum().item()
+    rhs = (gout[..., :3].double() * rgba[..., :3].double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    _, grads2 = _render(ops, s, grad=True, gout=gout)
+    assert torch.equal(grads["template"], grads2["template"])
+    _hooks.force_ray_centric_backward = True
+    try:
+        _, gr = _render(ops, s, slice(0, 1), grad=True, gout=gout[:1])
+    finally:
+        _hooks.force_ray_centric_backward = False
+    gt = grads["template"][:1]
+    assert (gr["template"] - gt).abs().max().item() <= 1e-3 * gt.abs().max().item()
+    for k in ("primpos", "primrot", "primscale"):
+        assert cosine(npf(gr[k]), npf(grads[k][:1])) >= 0.99999
 
 
 @pytest.fixture(scope="module")
