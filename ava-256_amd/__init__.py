@@ -19,7 +19,8 @@ The directory name contains a hyphen (it is the name the build contract asks for
 if its tensors are not on a HIP device or if libmvp_gfx950.so has not been built.
 """
 from .raydirs import ComputeRaydirs, compute_raydirs  # noqa: F401
-from .mvpraymarch import MVPRaymarch, build_accel, mvpraymarch  # noqa: F401
+from .mvpraymarch import MVPRaymarch, MVPRaymarchFromCameras, build_accel, mvpraymarch, mvpraymarch_from_cameras  # noqa: F401
 from .raymarcher import Raymarcher  # noqa: F401
 
-__all__ = ["compute_raydirs", "ComputeRaydirs", "mvpraymarch", "MVPRaymarch", "build_accel", "Raymarcher"]
+__all__ = ["compute_raydirs", "ComputeRaydirs", "mvpraymarch", "MVPRaymarch", "build_accel", "Raymarcher",
+           "mvpraymarch_from_cameras", "MVPRaymarchFromCameras"]

@@ -29,6 +29,10 @@ SIGNATURES = {
                            [_c_void_p] + [_c_int] * 3 + [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 6 + [_c_float] * 2 +
                            [_c_void_p] * 2),
 }
+# N,H,W,K | campos,camrot,focal,princpt,pixelcoords | volradius,stepsize | nodeaabb,primpos,primrot,primscale | TD,TH,TW |
+# tplate,rayrgba,raysat,rayaux,primlist_count,primlist | primlist_cap | fadescale,fadeexp | diag,stream
+SIGNATURES["mvp_march_forward_cams"] = (_c_int, [_c_int] * 4 + [_c_void_p] * 5 + [_c_float] * 2 + [_c_void_p] * 4 +
+                                        [_c_int] * 3 + [_c_void_p] * 6 + [_c_int] + [_c_float] * 2 + [_c_void_p] * 2)
 SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
 # N,H,W | rayrgba | rayrgb,rayalpha | stream     and     N,H,W | g_rgb,g_alpha | g_rgba | stream
@@ -42,12 +46,20 @@ SIGNATURES["mvp_prim_placement_backward"] = (_c_int, [_c_int] * 9 + [_c_float] +
 SIGNATURES["mvp_grads_sanitize_sqnorm"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_void_p])
 # ntensors | grads, numels | sqnorm | max_norm | total_norm | stream
 SIGNATURES["mvp_grads_clip_scale"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 2)
-ABI_VERSION = 6
+ABI_VERSION = 8
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]
 
 _lib = None
+
+
+def use_library(path=None):
+    """Tests / timing experiments only: bind a different build of the SAME ABI (build_variants/...), or go back to the
+    product library with path=None.  Takes effect on the next get_lib()."""
+    global _lib, LIB_PATH
+    LIB_PATH = path or os.path.join(_HERE, "libmvp_gfx950.so")
+    _lib = None
 
 
 def get_lib():

@@ -46,5 +46,25 @@ def build(force=False, verbose=False):
     return LIB
 
 
+VARIANT_DIR = os.path.join(ROOT, "build_variants")
+
+
+def build_variant(name, defines, force=False):
+    """Compile a NON-product variant of the library into build_variants/libmvp_<name>.so (tests and timing
+    experiments only, e.g. defines=["MVP_DEBUG_HOOKS"] for the build that honours the MVP_DEBUG_* environment)."""
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    out = os.path.join(VARIANT_DIR, "libmvp_%s.so" % name)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = [_hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out + ".tmp"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

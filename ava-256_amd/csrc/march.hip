@@ -45,6 +45,19 @@ constexpr int kMaxList = 512;     // reference hit-list cap (mvpraymarch_kernel.
 constexpr int kRecSlots = 64;     // SRT records staged in LDS (first 64 candidates); beyond: scalar global loads
 constexpr int kStartDepth = 10;   // the BFS tests every node of this depth first (implicit frontier, <= 1024 nodes)
 constexpr int kNoSlot = 255;
+// Lane-independent forward sweep (see march_packet): per-ray crossing table in LDS, kFastCross rows of 64 lanes.
+// Row index 31 is the null link, so a ray can hold at most min(kFastCross, 31) crossings; packets beyond any of the
+// limits below are marched by the slot-synchronous sweep instead (same results, slower).
+#ifndef MVP_FAST_CROSS
+#define MVP_FAST_CROSS 24
+#endif
+constexpr int kFastCross = MVP_FAST_CROSS;
+constexpr int kFastMaxCross = kFastCross < 31 ? kFastCross : 31;
+constexpr int kFastSlots = 64;    // list slots (6-bit field; also: every record is LDS-resident)
+constexpr int kFastCand = 128;    // BVH candidates (two registers per lane)
+constexpr int kFastMaxLen = 64;   // lattice steps of one crossing (6-bit field)
+constexpr int kFastMaxStep = 32767;  // largest lattice-step index (15-bit field)
+constexpr uint32_t kNullLink = 31u;
 
 struct MarchParams {
     int N, H, W, K;
@@ -52,6 +65,10 @@ struct MarchParams {
     int tiles_x, tiles_y, chunk;  // 8x8 packets per image row / column; packets per (image, XCD) chunk
     float stepsize, fadescale, fadeexp;
     const float *raypos, *raydir, *tminmax, *nodeaabb, *primpos, *primrot, *primscale, *tplate;
+    // forward only, instead of raypos/raydir/tminmax (all three null then): rays are made in the kernel from the cameras
+    // with the arithmetic of raydirs_kernel (mvp_device.h: ray_from_camera) -- mvp_march_forward_cams
+    const float *campos, *camrot, *focal, *princpt, *pixelcoords;
+    float volradius;
     int WD, WH, WW;                              // warp-field grid (algo 1), 0 when absent
     const float *warp;                           // [N,K,WD,WH,WW,3] or null
     float *grad_warp;                            // backward, algo 1
@@ -61,18 +78,32 @@ struct MarchParams {
     uint32_t *diag;
     // forward -> backward hand-off (grad mode only; all may be null)
     uint32_t *rayaux;     // [N,H,W,4]: {satkey, bits(alpha before the saturating sample), first step, bits(tend)}
-    uint32_t *pl_count;   // [N*K + 3]: packets appended per primitive; then flags (kFlag*), bits(G), bits(Rmax)
+    uint32_t *pl_count;   // [N*K + 3 + N*tiles]: packets appended per primitive; flags (kFlag*), reserved, bits(Rmax);
+                          // then per ray packet bits(max |grad_rayrgba|) of the current backward
     uint2 *pl_list;       // [N*K, pl_cap]: {(packet << 9) | list slot, lo | hi << 16}
     int pl_cap;
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
     int total_packets;    // 8 * chunk * N
-    int debug_force_dfs;  // tests: MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
-    int debug_stage;      // profiling only (MVP_DEBUG_STAGE): 11 stop after the root test, 12 after the ancestor pre-cull,
+    // Only read by builds with -DMVP_DEBUG_HOOKS (tools/exp_variants.sh); the product library ignores the environment.
+    int debug_force_dfs;  // MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
+    int debug_slot_sweep; // MVP_DEBUG_SLOT_SWEEP=1 makes every packet take the slot-synchronous forward sweep
+    int debug_stage;      // profiling (MVP_DEBUG_STAGE): 11 stop after the root test, 12 after the ancestor pre-cull,
                           // 13 after the implicit level, 1 after traversal, 2 after the exact pass, 3 no sampling
 };
+#ifdef MVP_DEBUG_HOOKS
+#define MVP_DEBUG_STAGE(P_) ((P_).debug_stage)
+#define MVP_DEBUG_FORCE_DFS(P_) ((P_).debug_force_dfs != 0)
+#define MVP_DEBUG_SLOT_SWEEP(P_) ((P_).debug_slot_sweep != 0)
+#else
+#define MVP_DEBUG_STAGE(P_) 0
+#define MVP_DEBUG_FORCE_DFS(P_) false
+#define MVP_DEBUG_SLOT_SWEEP(P_) false
+#endif
 
 constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than pl_cap packets
 constexpr uint32_t kFlagGlobal = 2u;        // a packet produced step indices that do not fit the packed keys
+constexpr uint32_t kFlagBwdHandoff = 4u;    // THIS backward handed a primitive to the ray-centric kernel (cleared per call)
+constexpr uint32_t kCountDead = 0x80000000u;  // pl_count bit 31: "handed over by this backward" (cleared per call)
 constexpr uint32_t kNoSat = 0xffffffffu;
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
@@ -89,11 +120,12 @@ struct Rec {  // one primitive's transform, wave-uniform while it is being proce
 
 // LDS image of a record, 4 x float4 per list slot, ordered so that the 16-byte reads deliver the register PAIRS the
 // packed-fp32 box transform wants:  (r0.x r0.y r1.x r1.y) (r2.x r2.y pos.x pos.y) (r0.z r1.z r2.z pos.z) (s.x s.y s.z 0)
-__device__ __forceinline__ void rec_to_lds(float4 *s_rec, int slot, const Rec &q) {
+// (the spare word carries the primitive index k, so a lane that picks up a record needs no second lookup)
+__device__ __forceinline__ void rec_to_lds(float4 *s_rec, int slot, const Rec &q, int k) {
     s_rec[slot * 4 + 0] = make_float4(q.r0.x, q.r0.y, q.r1.x, q.r1.y);
     s_rec[slot * 4 + 1] = make_float4(q.r2.x, q.r2.y, q.pos.x, q.pos.y);
     s_rec[slot * 4 + 2] = make_float4(q.r0.z, q.r1.z, q.r2.z, q.pos.z);
-    s_rec[slot * 4 + 3] = make_float4(q.scale.x, q.scale.y, q.scale.z, 0.f);
+    s_rec[slot * 4 + 3] = make_float4(q.scale.x, q.scale.y, q.scale.z, __int_as_float(k));
 }
 __device__ __forceinline__ Rec rec_from_lds(const float4 *s_rec, int slot) {
     const float4 a = s_rec[slot * 4 + 0], b = s_rec[slot * 4 + 1], c = s_rec[slot * 4 + 2], d = s_rec[slot * 4 + 3];
@@ -130,14 +162,45 @@ __device__ __forceinline__ RecP recp_of(const Rec &q) {
     r.r0z = q.r0.z, r.r1z = q.r1.z, r.r2z = q.r2.z, r.pz = q.pos.z, r.sz = q.scale.z;
     return r;
 }
+// ---- arithmetic shared by the two forward sweeps -------------------------------------------------------------------
+// Both march schedules of the forward (lane-independent and slot-synchronous) must give every ray the SAME bits: a
+// packet picks one or the other by its size, and a ray's value may not depend on the packet it sits in.  hipcc
+// contracts a*b+c into an FMA per call site, so the same inline function can round differently in two places (it
+// did: ~1 ulp on a third of the rays).  Everything both sweeps evaluate per sample is therefore written with EXPLICIT
+// fused operations under `fp contract(off)`: box transform, ray position, fade, trilinear weights and interpolation,
+// compositing.
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+
 // primtransf.h:119-132 for a direction (no translation) and for a point
 __device__ __forceinline__ Y3 box_dir(const RecP &q, v2f vxy, float vz) {
+#pragma clang fp contract(off)
     Y3 y;
-    y.xy = (q.r0xy * vxy.x + q.r1xy * vxy.y + q.r2xy * vz) * q.sxy;
-    y.z = (q.r0z * vxy.x + q.r1z * vxy.y + q.r2z * vz) * q.sz;
+    y.xy = pk_fma(q.r2xy, splat(vz), pk_fma(q.r1xy, splat(vxy.y), q.r0xy * splat(vxy.x))) * q.sxy;
+    y.z = __builtin_fmaf(q.r2z, vz, __builtin_fmaf(q.r1z, vxy.y, q.r0z * vxy.x)) * q.sz;
     return y;
 }
-__device__ __forceinline__ Y3 box_point(const RecP &q, v2f xxy, float xz) { return box_dir(q, xxy - q.pxy, xz - q.pz); }
+__device__ __forceinline__ Y3 box_point(const RecP &q, v2f xxy, float xz) {
+#pragma clang fp contract(off)
+    return box_dir(q, xxy - q.pxy, xz - q.pz);
+}
+// x = o + d * t at lattice step s, t = tmin + s * dt  (the reference accumulates, subset_kernel.h:95-96)
+__device__ __forceinline__ float lattice_t(int s, float dt, float tmin) { return __builtin_fmaf((float)s, dt, tmin); }
+__device__ __forceinline__ void ray_point(v2f oxy, float oz, v2f dxy, float dz, float t, v2f &xxy, float &xz) {
+    xxy = pk_fma(dxy, splat(t), oxy);
+    xz = __builtin_fmaf(dz, t, oz);
+}
+// primaccum.h:63-79: returns true when this sample saturates the ray (contrib is what was added to alpha)
+__device__ __forceinline__ bool composite(float4 &rgba, const float4 &v, float dt, float &contrib) {
+#pragma clang fp contract(off)
+    const float newalpha = __builtin_fmaf(v.w, dt, rgba.w);
+    contrib = fminf(newalpha, 1.f) - rgba.w;
+    rgba.x = __builtin_fmaf(v.x, contrib, rgba.x);
+    rgba.y = __builtin_fmaf(v.y, contrib, rgba.y);
+    rgba.z = __builtin_fmaf(v.z, contrib, rgba.z);
+    rgba.w = rgba.w + contrib;
+    return newalpha >= 1.f;
+}
 __device__ __forceinline__ bool strictly_inside(const Y3 &y) {  // primtransf.h:112-117
     return fabsf(y.xy.x) < 1.f && fabsf(y.xy.y) < 1.f && fabsf(y.z) < 1.f;
 }
@@ -211,26 +274,64 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d)
 // Forward sample of one slab at box coordinate y (strictly inside (-1,1)^3): fade (primsampler.h:48-51) times the
 // channels-last trilinear lookup (utils.h:414-468; base corner clamped so that all 8 corners are in bounds, which
 // gives the same value as the reference's zero-padded form).  Returns (r, g, b, alpha * fade).
+// fade = exp(-fadescale * sum |y_i|^fadeexp)  (primsampler.h:48-51)
+template <bool FADE8>
+__device__ __forceinline__ float fade_pinned(f3 y, float fadescale, float fadeexp) {
+#pragma clang fp contract(off)
+    float e;
+    if (FADE8) {
+        const f3 y2 = y * y, y4 = y2 * y2;
+        e = __builtin_fmaf(y4.z, y4.z, __builtin_fmaf(y4.y, y4.y, y4.x * y4.x));
+    } else {
+        e = (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp)) + fast_pow(fabsf(y.z), fadeexp);
+    }
+    return fast_exp(-fadescale * e);
+}
+struct Tri {  // base corner (clamped so that all 8 corners are in bounds) and the 8 corner weights
+    int x0, y0, z0;
+    float w000, w001, w010, w011, w100, w101, w110, w111;
+};
+__device__ __forceinline__ Tri tri_setup(f3 y, float mx, float my, float mz, int TW, int TH, int TD) {
+#pragma clang fp contract(off)
+    const float ix = ((y.x + 1.f) * 0.5f) * mx, iy = ((y.y + 1.f) * 0.5f) * my, iz = ((y.z + 1.f) * 0.5f) * mz;
+    Tri t;
+    t.x0 = min((int)floorf(ix), TW - 2), t.y0 = min((int)floorf(iy), TH - 2), t.z0 = min((int)floorf(iz), TD - 2);
+    const float wx1 = ix - (float)t.x0, wx0 = (float)(t.x0 + 1) - ix;
+    const float wy1 = iy - (float)t.y0, wy0 = (float)(t.y0 + 1) - iy;
+    const float wz1 = iz - (float)t.z0, wz0 = (float)(t.z0 + 1) - iz;
+    const float wyz00 = wy0 * wz0, wyz10 = wy1 * wz0, wyz01 = wy0 * wz1, wyz11 = wy1 * wz1;
+    t.w000 = wx0 * wyz00, t.w001 = wx1 * wyz00, t.w010 = wx0 * wyz10, t.w011 = wx1 * wyz10;
+    t.w100 = wx0 * wyz01, t.w101 = wx1 * wyz01, t.w110 = wx0 * wyz11, t.w111 = wx1 * wyz11;
+    return t;
+}
+// sum_c w_c * corner_c on the (x,y)/(z,w) register pairs the 16-byte loads deliver, in corner order 000,001,..,111
+__device__ __forceinline__ float4 tri_interp(const Tri &t, const float4 &c000, const float4 &c001, const float4 &c010,
+                                             const float4 &c011, const float4 &c100, const float4 &c101,
+                                             const float4 &c110, const float4 &c111) {
+#pragma clang fp contract(off)
+#define MVP_L(C_) v2f{(C_).x, (C_).y}
+#define MVP_H(C_) v2f{(C_).z, (C_).w}
+    v2f vl = MVP_L(c000) * splat(t.w000), vh = MVP_H(c000) * splat(t.w000);
+    vl = pk_fma(MVP_L(c001), splat(t.w001), vl), vh = pk_fma(MVP_H(c001), splat(t.w001), vh);
+    vl = pk_fma(MVP_L(c010), splat(t.w010), vl), vh = pk_fma(MVP_H(c010), splat(t.w010), vh);
+    vl = pk_fma(MVP_L(c011), splat(t.w011), vl), vh = pk_fma(MVP_H(c011), splat(t.w011), vh);
+    vl = pk_fma(MVP_L(c100), splat(t.w100), vl), vh = pk_fma(MVP_H(c100), splat(t.w100), vh);
+    vl = pk_fma(MVP_L(c101), splat(t.w101), vl), vh = pk_fma(MVP_H(c101), splat(t.w101), vh);
+    vl = pk_fma(MVP_L(c110), splat(t.w110), vl), vh = pk_fma(MVP_H(c110), splat(t.w110), vh);
+    vl = pk_fma(MVP_L(c111), splat(t.w111), vl), vh = pk_fma(MVP_H(c111), splat(t.w111), vh);
+#undef MVP_L
+#undef MVP_H
+    return make_float4(vl.x, vl.y, vh.x, vh.y);
+}
+
 template <bool FADE8>
 __device__ __forceinline__ float4 sample_slab(const float *__restrict__ Tk, f3 y, int TD, int TH, int TW,
                                               float fadescale, float fadeexp) {
-    float fade;
-    if (FADE8) {
-        const f3 y2 = y * y, y4 = y2 * y2;
-        fade = fast_exp(-fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
-    } else {
-        fade = fast_exp(-fadescale * (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp) +
-                                      fast_pow(fabsf(y.z), fadeexp)));
-    }
-    const float ix = (y.x + 1.f) * 0.5f * (float)(TW - 1);
-    const float iy = (y.y + 1.f) * 0.5f * (float)(TH - 1);
-    const float iz = (y.z + 1.f) * 0.5f * (float)(TD - 1);
-    const int x0 = min((int)floorf(ix), TW - 2), y0 = min((int)floorf(iy), TH - 2), z0 = min((int)floorf(iz), TD - 2);
-    const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
-    const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
-    const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+#pragma clang fp contract(off)
+    const float fade = fade_pinned<FADE8>(y, fadescale, fadeexp);
+    const Tri t = tri_setup(y, (float)(TW - 1), (float)(TH - 1), (float)(TD - 1), TW, TH, TD);
     const int sW = 4, sH = TW * 4, sD = TH * TW * 4;
-    const float *Tp = Tk + (size_t)z0 * sD + (size_t)y0 * sH + (size_t)x0 * sW;
+    const float *Tp = Tk + (size_t)t.z0 * sD + (size_t)t.y0 * sH + (size_t)t.x0 * sW;
     const float4 c000 = *reinterpret_cast<const float4 *>(Tp);
     const float4 c001 = *reinterpret_cast<const float4 *>(Tp + sW);
     const float4 c010 = *reinterpret_cast<const float4 *>(Tp + sH);
@@ -239,17 +340,8 @@ __device__ __forceinline__ float4 sample_slab(const float *__restrict__ Tk, f3 y
     const float4 c101 = *reinterpret_cast<const float4 *>(Tp + sD + sW);
     const float4 c110 = *reinterpret_cast<const float4 *>(Tp + sD + sH);
     const float4 c111 = *reinterpret_cast<const float4 *>(Tp + sD + sH + sW);
-    const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w011 = wx1 * wy1 * wz0,
-                w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
-    float4 v;
-    v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 + c101.x * w101 +
-          c110.x * w110 + c111.x * w111;
-    v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 + c101.y * w101 +
-          c110.y * w110 + c111.y * w111;
-    v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 + c101.z * w101 +
-          c110.z * w110 + c111.z * w111;
-    v.w = (c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 + c101.w * w101 +
-           c110.w * w110 + c111.w * w111) * fade;
+    float4 v = tri_interp(t, c000, c001, c010, c011, c100, c101, c110, c111);
+    v.w = v.w * fade;
     return v;
 }
 
@@ -259,39 +351,20 @@ __device__ __forceinline__ float4 sample_slab(const float *__restrict__ Tk, f3 y
 template <bool FADE8, int TS>
 __device__ __forceinline__ float4 sample_slab_c(const float *__restrict__ Timg, uint32_t kbyte, f3 y, float fadescale,
                                                 float fadeexp) {
-    float fade;
-    if (FADE8) {
-        const f3 y2 = y * y, y4 = y2 * y2;
-        fade = fast_exp(-fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
-    } else {
-        fade = fast_exp(-fadescale * (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp) +
-                                      fast_pow(fabsf(y.z), fadeexp)));
-    }
+#pragma clang fp contract(off)
+    const float fade = fade_pinned<FADE8>(y, fadescale, fadeexp);
     constexpr float m = (float)(TS - 1);
-    const float ix = (y.x + 1.f) * 0.5f * m, iy = (y.y + 1.f) * 0.5f * m, iz = (y.z + 1.f) * 0.5f * m;
-    const int x0 = min((int)floorf(ix), TS - 2), y0 = min((int)floorf(iy), TS - 2), z0 = min((int)floorf(iz), TS - 2);
-    const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
-    const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
-    const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+    const Tri t = tri_setup(y, m, m, m, TS, TS, TS);
     constexpr int bW = 16, bH = TS * 16, bD = TS * TS * 16;  // byte strides
-    const uint32_t off = kbyte + (uint32_t)(z0 * bD + y0 * bH + x0 * bW);
+    const uint32_t off = kbyte + (uint32_t)(t.z0 * bD + t.y0 * bH + t.x0 * bW);
     const char *pc = reinterpret_cast<const char *>(Timg) + (size_t)off;
 #define MVP_C(O_) (*reinterpret_cast<const float4 *>(pc + (O_)))
     const float4 c000 = MVP_C(0), c001 = MVP_C(bW), c010 = MVP_C(bH), c011 = MVP_C(bH + bW);
     const float4 c100 = MVP_C(bD), c101 = MVP_C(bD + bW), c110 = MVP_C(bD + bH), c111 = MVP_C(bD + bH + bW);
 #undef MVP_C
-    const float wyz00 = wy0 * wz0, wyz10 = wy1 * wz0, wyz01 = wy0 * wz1, wyz11 = wy1 * wz1;
-    const float w000 = wx0 * wyz00, w001 = wx1 * wyz00, w010 = wx0 * wyz10, w011 = wx1 * wyz10, w100 = wx0 * wyz01,
-                w101 = wx1 * wyz01, w110 = wx0 * wyz11, w111 = wx1 * wyz11;
-#define MVP_L(C_) v2f{(C_).x, (C_).y}
-#define MVP_H(C_) v2f{(C_).z, (C_).w}
-    const v2f vl = MVP_L(c000) * w000 + MVP_L(c001) * w001 + MVP_L(c010) * w010 + MVP_L(c011) * w011 +
-                   MVP_L(c100) * w100 + MVP_L(c101) * w101 + MVP_L(c110) * w110 + MVP_L(c111) * w111;
-    const v2f vh = MVP_H(c000) * w000 + MVP_H(c001) * w001 + MVP_H(c010) * w010 + MVP_H(c011) * w011 +
-                   MVP_H(c100) * w100 + MVP_H(c101) * w101 + MVP_H(c110) * w110 + MVP_H(c111) * w111;
-#undef MVP_L
-#undef MVP_H
-    return make_float4(vl.x, vl.y, vh.x, vh.y * fade);
+    float4 v = tri_interp(t, c000, c001, c010, c011, c100, c101, c110, c111);
+    v.w = v.w * fade;
+    return v;
 }
 
 // ---- warp-field path (algo 1: PrimSamplerTW<true>, primsampler.h:53-58,82-88) -------------------------------------
@@ -385,7 +458,8 @@ __device__ __forceinline__ bool lane_step_range(float tn, float tf, float tmin, 
 
 template <bool BWD, bool FADE8, bool WARP, int TS>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
-                                             const bool emit_all) {
+                                             uint32_t *s_tab, const bool emit_all) {
+    constexpr bool FAST = !BWD && !WARP;  // the lane-independent sweep exists for the plain forward only
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt(lane);
 
@@ -410,11 +484,23 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     float tmin = INFINITY, tmax = -INFINITY;
     if (inimg) {
-        o = ld3(p.raypos + r * 3);
-        d = ld3(p.raydir + r * 3);
-        const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
-        tmin = tt.x;
-        tmax = tt.y;
+        if (!BWD && p.campos != nullptr) {  // (wave-uniform) rays from the camera: no ray tensors are read
+            float fpx = (float)px, fpy = (float)py;
+            if (p.pixelcoords) {
+                const float2 pc = reinterpret_cast<const float2 *>(p.pixelcoords)[r];
+                fpx = pc.x, fpy = pc.y;
+            }
+            const float *cp = p.campos + (size_t)n * 3, *fo = p.focal + (size_t)n * 2, *pc2 = p.princpt + (size_t)n * 2;
+            const CamRay c = ray_from_camera(mk3(cload(cp), cload(cp + 1), cload(cp + 2)), p.camrot + (size_t)n * 9,
+                                             cload(fo), cload(fo + 1), cload(pc2), cload(pc2 + 1), fpx, fpy, p.volradius);
+            o = c.o, d = c.d, tmin = c.tmin, tmax = c.tmax;
+        } else {
+            o = ld3(p.raypos + r * 3);
+            d = ld3(p.raydir + r * 3);
+            const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
+            tmin = tt.x;
+            tmax = tt.y;
+        }
     }
     // a ray can only take a sample at t in [tmin, tmax + 1e-5) (subset_kernel.h:63-64,84)
     const bool active = inimg && (tmin < tmax + 1e-5f);
@@ -425,6 +511,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     float wbefore = 0.f;       // alpha just before it
     int nh = 0;            // final list length (wave-uniform)
     int ncand = 0;
+    bool fast = false;     // wave-uniform: this packet is marched by the lane-independent sweep
+    int kk0 = 0, kk1 = 0;  // candidates `lane` and `lane + 64` (lane-independent mode)
 
     if (__ballot(active) != 0ull) {
         // ---------------- packet bounds (6-step butterflies, once per packet) ----------------
@@ -452,7 +540,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             const float2 *ap = reinterpret_cast<const float2 *>(A);  // root AABB, wave-uniform
             const float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
             if (!packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y)) ncur = 0;
-            if (p.debug_stage == 11) ncur = 0;
+            if (MVP_DEBUG_STAGE(p) == 11) ncur = 0;
         }
         // Coarse pre-cull of the implicit level: its nodes are grouped 32 per ancestor 5 levels up (<= 32 ancestors,
         // one lane each); groups whose ancestor fails the packet test are skipped without touching their boxes.
@@ -466,7 +554,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 ok = packet_hits_box(pb, a0.x, a0.y, a1.x, a1.y, a2.x, a2.y);
             }
             anc_pass = (unsigned)__ballot(ok);
-            if (anc_pass == 0u || p.debug_stage == 12) ncur = 0;
+            if (anc_pass == 0u || MVP_DEBUG_STAGE(p) == 12) ncur = 0;
         }
         for (int dep = ds; ncur > 0; ++dep) {
             int nnext = 0;
@@ -491,7 +579,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 if (e2 && pos + 1 < kMaxList) nxt[pos + 1] = 2 * g + 2;
                 nnext += __popcll(m1) + __popcll(m2);
             }
-            if (nnext > kMaxList || p.debug_force_dfs) {
+            if (nnext > kMaxList || MVP_DEBUG_FORCE_DFS(p)) {
                 frontier_ovf = true;
                 break;
             }
@@ -500,7 +588,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             cur = nxt;
             nxt = t;
             ncur = nnext;
-            if (p.debug_stage == 13) ncur = 0;
+            if (MVP_DEBUG_STAGE(p) == 13) ncur = 0;
             if (dep >= dmax) break;
         }
         ncand = ncur;  // entries of `cur` are ~node of tested leaves, in DFS (left-to-right) order
@@ -566,34 +654,145 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             cur = cand;
         }
 
-        // move candidates into s_b as primitive indices (cur may be either buffer)
+        // ---- candidates leave the frontier buffers (cur may be either one) ----
+        // Lane-independent mode (FAST, <= kFastCand candidates): they stay in two registers per lane, because the
+        // frontier region is about to become the per-ray crossing table.  Otherwise: s_b, as primitive indices.
+        fast = FAST && ncand > 0 && ncand <= kFastCand && !MVP_DEBUG_SLOT_SWEEP(p);
         if (ncand > 0) {
-            int kk[kMaxList / kWave];
+            if (fast) {
+                kk0 = lane < ncand ? (~cur[lane]) - (K - 1) : 0;
+                kk1 = lane + kWave < ncand ? (~cur[lane + kWave]) - (K - 1) : 0;
+                __syncthreads();
+            } else {
+                int kk[kMaxList / kWave];
 #pragma unroll
-            for (int c = 0; c < kMaxList / kWave; ++c) {
-                const int idx = c * kWave + lane;
-                kk[c] = idx < ncand ? (~cur[idx]) - (K - 1) : 0;
-            }
-            __syncthreads();
+                for (int c = 0; c < kMaxList / kWave; ++c) {
+                    const int idx = c * kWave + lane;
+                    kk[c] = idx < ncand ? (~cur[idx]) - (K - 1) : 0;
+                }
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < kMaxList / kWave; ++c) {
-                const int idx = c * kWave + lane;
-                if (idx < ncand) s_b[idx] = kk[c];
+                for (int c = 0; c < kMaxList / kWave; ++c) {
+                    const int idx = c * kWave + lane;
+                    if (idx < ncand) s_b[idx] = kk[c];
+                }
+                kk0 = kk[0];
             }
             // stage the SRT records of the first 64 candidates: lanes over candidates, one gather round trip
-            if (lane < ncand && lane < kRecSlots) {
-                rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk[0]));
-            }
+            if (lane < ncand && lane < kRecSlots) rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk0), kk0);
             __syncthreads();
         }
     }
 
-    if (p.debug_stage == 1) ncand = 0;
+    if (MVP_DEBUG_STAGE(p) == 1) ncand = 0;
     const v2f oxy = {o.x, o.y}, dxy = {d.x, d.y};
     // ---------------- exact per-ray leaf test (utils.h:744-761), lanes over rays ----------------
     float rtmin = INFINITY, rtmax = -INFINITY;
     bool ranges_ok = true;  // false when a step index does not fit the packed 16-bit range
-    for (int c = 0; c < ncand; ++c) {
+    // lane-independent mode: list entry (k) and packed packet range of slot `lane`, and this ray's crossing list
+    int ent0 = 0, rg0 = 0;
+    uint32_t head = kNullLink;
+    int ncross = 0;
+    if (FAST && fast) {
+        // Same test as below, and in addition every ray records ITS OWN crossings (slot, first step, step count) in
+        // the LDS table s_tab[j * 64 + lane], j = 0,1,.. in list order, linked in order of the first step:
+        //   entry = slot | next << 6 | (steps - 1) << 11 | first step << 17.
+        // Records are compacted so that s_rec[slot] is the record of list slot `slot`.
+        uint32_t tailj = kNullLink;
+        int taillo = -1;
+        bool lfail = false;
+        bool wfail = false;
+        for (int c = 0; c < ncand; ++c) {
+            const int k = c < kWave ? __builtin_amdgcn_readlane(kk0, c) : __builtin_amdgcn_readlane(kk1, c - kWave);
+            const bool inlds = c < kRecSlots;
+            Rec qg;
+            if (!inlds) qg = rec_from_global(pp, pr, ps, k);
+            const RecP q = inlds ? recp_from_lds(s_rec, c) : recp_of(qg);
+            const Y3 r0p = box_point(q, oxy, o.z), rdp = box_dir(q, dxy, d.z);  // primtransf.h:134-153
+            const f3 r0 = mk3(r0p.xy.x, r0p.xy.y, r0p.z), rd = mk3(rdp.xy.x, rdp.xy.y, rdp.z);
+            const f3 ird = mk3(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+            const f3 t0 = mk3((-1.f - r0.x) * ird.x, (-1.f - r0.y) * ird.y, (-1.f - r0.z) * ird.z);
+            const f3 t1 = mk3((1.f - r0.x) * ird.x, (1.f - r0.y) * ird.y, (1.f - r0.z) * ird.z);
+            const float tn = max3f(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+            const float tf = min3f(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z));
+            const bool hit = active && (tn <= tf);
+            if (hit) {
+                rtmin = fminf(rtmin, tn);
+                rtmax = fmaxf(rtmax, tf);
+            }
+            int lo = 0x7fffffff, hi = -1;
+            const bool some = hit && lane_step_range(tn, tf, tmin, tmax, dt, lo, hi);
+            if (!some) lo = 0x7fffffff, hi = -1;
+            if (__ballot(some) != 0ull) {  // wave-uniform
+                const int wlo = uni(wave_min(lo)), whi = uni(wave_max(hi));
+                if (nh >= kFastSlots || whi > kFastMaxStep) {
+                    wfail = true;
+                    break;
+                }
+                if (lane == nh) {
+                    ent0 = k;
+                    rg0 = wlo | (whi << 16);
+                }
+                // the record moves to its list slot (nh <= c: nothing unread is overwritten; one wave, in-order LDS)
+                if (inlds) {
+                    if (nh != c && lane < 4) s_rec[nh * 4 + lane] = s_rec[c * 4 + lane];
+                } else if (lane == 0) {
+                    rec_to_lds(s_rec, nh, qg, k);
+                }
+                if (some) {
+                    const int len = hi - lo + 1;
+                    if (ncross >= kFastMaxCross || len > kFastMaxLen) {
+                        lfail = true;
+                    } else {
+                        // sorted insert by first step; most crossings arrive in increasing order of depth within a
+                        // shell, so the tail test usually avoids the walk
+                        const uint32_t jn = (uint32_t)ncross;
+                        uint32_t prev = kNullLink, nx = kNullLink;
+                        if (lo >= taillo) {
+                            prev = tailj;
+                        } else {
+                            uint32_t cj = head;
+                            while (true) {  // ends: the tail's first step is > lo
+                                const uint32_t ce = s_tab[cj * kWave + lane];
+                                if ((int)(ce >> 17) > lo) {
+                                    nx = cj;
+                                    break;
+                                }
+                                prev = cj;
+                                cj = (ce >> 6) & 31u;
+                            }
+                        }
+                        s_tab[jn * kWave + lane] =
+                            (uint32_t)nh | (nx << 6) | ((uint32_t)(len - 1) << 11) | ((uint32_t)lo << 17);
+                        if (prev == kNullLink) {
+                            head = jn;
+                        } else {
+                            const uint32_t pe = s_tab[prev * kWave + lane];
+                            s_tab[prev * kWave + lane] = (pe & ~(31u << 6)) | (jn << 6);
+                        }
+                        if (nx == kNullLink) {
+                            tailj = jn;
+                            taillo = lo;
+                        }
+                        ++ncross;
+                    }
+                }
+                ++nh;
+            }
+        }
+        if (wfail || __ballot(lfail) != 0ull) {
+            // over one of the limits: start again in slot-synchronous mode (candidates back to LDS, records re-staged)
+            fast = false;
+            rtmin = INFINITY, rtmax = -INFINITY;
+            nh = 0;
+            __syncthreads();
+            if (lane < ncand) s_b[lane] = kk0;
+            if (lane + kWave < ncand) s_b[lane + kWave] = kk1;
+            if (lane < ncand && lane < kRecSlots) rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk0), kk0);
+            __syncthreads();
+        }
+    }
+    for (int c = 0; c < ((FAST && fast) ? 0 : ncand); ++c) {
         const int k = uni(s_b[c]);
         const int slot = c < kRecSlots ? c : kNoSlot;
         const RecP q = (c < kRecSlots) ? recp_from_lds(s_rec, c) : recp_of(rec_from_global(pp, pr, ps, k));
@@ -631,20 +830,31 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
     __syncthreads();
 
-    if (p.debug_stage == 2) nh = 0;
+    if (MVP_DEBUG_STAGE(p) == 2) nh = 0;
     // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
     if (!BWD && p.pl_count != nullptr && nh > 0) {
         uint32_t *flags = p.pl_count + (size_t)p.N * K;
-        for (int j = lane; j < nh; j += kWave) {
-            const int k = s_b[j] & 0xffffff;
-            const size_t pk = (size_t)n * K + k;
-            const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
-            if (idx < (uint32_t)p.pl_cap)
-                p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j]);
-            else
-                raise_flag(flags, kFlagListOverflow);
+        if (FAST && fast) {
+            if (lane < nh) {
+                const size_t pk = (size_t)n * K + ent0;
+                const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
+                if (idx < (uint32_t)p.pl_cap)
+                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)lane, (uint32_t)rg0);
+                else
+                    raise_flag(flags, kFlagListOverflow);
+            }
+        } else {
+            for (int j = lane; j < nh; j += kWave) {
+                const int k = s_b[j] & 0xffffff;
+                const size_t pk = (size_t)n * K + k;
+                const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
+                if (idx < (uint32_t)p.pl_cap)
+                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j]);
+                else
+                    raise_flag(flags, kFlagListOverflow);
+            }
+            if (!ranges_ok && lane == 0) raise_flag(flags, kFlagGlobal);
         }
-        if (!ranges_ok && lane == 0) raise_flag(flags, kFlagGlobal);
     }
 
     // ---------------- march ----------------
@@ -671,7 +881,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             atomicMax(p.diag + MVP_DIAG_MAX_LIST, (uint32_t)nh);
             atomicAdd(p.diag + MVP_DIAG_LIST_ENTRIES, (uint32_t)nh);
             atomicAdd(p.diag + MVP_DIAG_CANDIDATES, (uint32_t)ncand);
-            if (ncand > kRecSlots) atomicAdd(p.diag + MVP_DIAG_SLOWPATH_PACKETS, 1u);
+            if (!(FAST && fast)) atomicAdd(p.diag + MVP_DIAG_SLOWPATH_PACKETS, 1u);
         }
         const size_t V4 = (size_t)p.TD * p.TH * p.TW * 4;
         const float *T = p.tplate + (size_t)n * K * V4;
@@ -679,274 +889,232 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         const int sW = 4, sH = p.TW * 4, sD = p.TH * p.TW * 4;  // float strides of the channels-last slab
         const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
 
-        // step window of the packet
-        int s = uni(wave_min(incs));
-        int s_last;
-        {
-            int mylast = -1;
-            for (int j = lane; j < nh; j += kWave) mylast = max(mylast, ranges_ok ? ((s_a[j] >> 16) & 0xffff) : 0x7ffffffe);
-            s_last = uni(wave_max(mylast));
-            // no sample at or beyond t = tend: bound the sweep by the rays' own end as well
-            const int myend = has ? (int)fminf(floorf((tend - tmin) * fast_rcp(dt)) + 1.f, 1.0e9f) : -1;
-            s_last = min(s_last, uni(wave_max(myend)));
-        }
-        const int nchunks = (nh + kWave - 1) / kWave;
-        bool sat = false;
-        // list slot `lane` of chunk 0 (every packet of a head-like scene fits in it): range and entry in registers
-        const int rg0 = lane < nh ? s_a[lane] : 0;
-        const int ent0 = lane < nh ? s_b[lane] : 0;
-
-        while (s <= s_last) {
-            if (__ballot(has && !sat) == 0ull) break;  // every ray saturated (subset_kernel.h:76)
-            const float t = fmaf((float)s, dt, tmin);
-            const v2f xxy = dxy * t + oxy;
-            const f3 x = mk3(xxy.x, xxy.y, fmaf(d.z, t, o.z));
-            const bool inrange = has && s >= incs && t < tend;
-            bool anyslot = false;
-            int nextlo = 0x7fffffff;
-            for (int ch = 0; ch < nchunks; ++ch) {
-                const int j = ch * kWave + lane;
-                bool on = false;
-                if (j < nh) {
-                    const int rg = ch == 0 ? rg0 : s_a[j];
-                    const int lo = rg & 0xffff, hi = (rg >> 16) & 0xffff;
-                    on = !ranges_ok || (lo <= s && s <= hi);
-                    if (lo > s) nextlo = min(nextlo, lo);
-                }
-                unsigned long long m = __ballot(on);
-                anyslot = anyslot || (m != 0ull);
-                if (!BWD) {
-                    // Forward: (A) every active slot's inside test with the record broadcast from LDS -> per-lane
-                    // bitmask of the slots this ray is inside at this step; (B) every lane then consumes ITS OWN
-                    // slots in ascending list order, all lanes sampling at once (records gathered per lane).  On
-                    // head-like scenes the boxes active at one step cover mostly disjoint parts of the packet, so
-                    // (B) runs ~overlap-depth rounds instead of one round per active slot.
-                    unsigned long long mine = 0ull;
-                    while (m) {  // list entries of chunk 0 come from registers via v_readlane (no LDS round trip)
-                        const int bit = __ffsll((long long)m) - 1;
-                        m &= m - 1ull;
-                        const int ent = ch == 0 ? __builtin_amdgcn_readlane(ent0, bit) : uni(s_b[ch * kWave + bit]);
-                        const int slot = (ent >> 24) & 0xff;
-                        const RecP q = (slot != kNoSlot) ? recp_from_lds(s_rec, slot)
-                                                          : recp_of(rec_from_global(pp, pr, ps, ent & 0xffffff));
-                        const bool inside = inrange && !sat && strictly_inside(box_point(q, xxy, x.z));  // subset_kernel.h:84
-                        if (inside) mine |= 1ull << bit;
-                    }
-                    if (p.debug_stage == 3) mine = 0ull;
-                    while (__ballot(mine != 0ull) != 0ull) {
-                        if (mine != 0ull) {
-                            const int bit = __ffsll((long long)mine) - 1;
-                            mine &= mine - 1ull;
-                            const int ent = s_b[ch * kWave + bit];
-                            int k = ent & 0xffffff;
-                            const int slot = (ent >> 24) & 0xff;
-                            // Opaque on purpose: with the TS > 0 sampler below, hipcc (ROCm 7.2) dropped this mask and fed
-                            // the raw entry (slot bits included) to the 64-bit address of the record loads -> wild reads.
-                            asm volatile("; k = entry & 0xffffff" : "+v"(k));
-                            const RecP q = (slot != kNoSlot) ? recp_from_lds(s_rec, slot)
-                                                              : recp_of(rec_from_global(pp, pr, ps, k));
-                            const Y3 yp = box_point(q, xxy, x.z);
-                            const f3 y = mk3(yp.xy.x, yp.xy.y, yp.z);
-                            float4 v;
-                            if (WARP) {  // primsampler.h:48-63 with dowarp: fade from y0, template sampled at warp(y0)
-                                const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
-                                const f3 y1 = warp_lookup(p.warp + ((size_t)n * K + k) * VW3, y, p.WD, p.WH, p.WW);
-                                v = tplate_lookup_general(T + (size_t)k * V4, y1, p.TD, p.TH, p.TW);
-                                v.w *= fade_of<FADE8>(y, p.fadescale, p.fadeexp);
-                            } else {
-                                if constexpr (TS > 0)
-                                    v = sample_slab_c<FADE8, TS>(T, (uint32_t)k * (uint32_t)(TS * TS * TS * 16), y,
-                                                                 p.fadescale, p.fadeexp);
-                                else
-                                    v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale,
-                                                           p.fadeexp);
-                            }
-                            // ---- primaccum.h:63-79 ----
-                            const float newalpha = rgba.w + v.w * dt;
-                            const float contrib = fminf(newalpha, 1.f) - rgba.w;
-                            rgba.x += v.x * contrib;
-                            rgba.y += v.y * contrib;
-                            rgba.z += v.z * contrib;
-                            rgba.w += contrib;
-                            if (newalpha >= 1.f) {
-                                raysat = mk3(v.x, v.y, v.z);
-                                sat = true;
-                                satkey = ((uint32_t)s << 9) | (uint32_t)(ch * kWave + bit);
-                                wbefore = rgba.w - contrib;
-                                mine = 0ull;  // saturated: nothing after this sample is evaluated
-                            }
-                        }
-                    }
-                    continue;
-                }
-                while (m) {
-                    const int bit = __ffsll((long long)m) - 1;
-                    m &= m - 1ull;
-                    const int ent = uni(s_b[ch * kWave + bit]);
-                    const int k = ent & 0xffffff, slot = (ent >> 24) & 0xff;
-                    const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
-                    const f3 xmt = x - q.pos;
-                    const f3 rxmt = rot_rows(q, xmt);
-                    const f3 y = rxmt * q.scale;
-                    const bool inside = inrange && !sat && y.x > -1.f && y.x < 1.f && y.y > -1.f && y.y < 1.f &&
-                                        y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
-                    if (__ballot(inside) == 0ull) continue;
-                    // fallback backward: only primitives the primitive-centric kernel could not own
-                    const bool emit = !BWD || emit_all || (p.pl_count[(size_t)n * K + k] > (uint32_t)p.pl_cap);
-
-                    f3 gy = mk3(0.f, 0.f, 0.f);  // BWD: dL/dy of this lane's sample (0 when not inside)
-                    if (BWD && WARP && inside) {
-                        // ---- warp-field sampler, backward (primsampler.h:68-91 with dowarp; utils.h:504-643 twice) ----
-                        const float fade = fade_of<FADE8>(y, p.fadescale, p.fadeexp);
-                        f3 ypow;
-                        if (FADE8) {
-                            const f3 y2 = y * y, y4 = y2 * y2;
-                            ypow = y4 * y2 * y;
+        if (FAST && fast) {
+            // ---- lane-independent sweep ----------------------------------------------------------------------
+            // Every ray walks ITS OWN samples in the reference's order (lattice step ascending, list slot ascending
+            // within a step: subset_kernel.h:76-97) at its own pace: no lane waits for the packet's step counter, and
+            // the inside test runs only where the ray's own step range says a sample can be.  `act` = my crossings
+            // that contain step s (bit j = my j-th crossing in list order), `cur` = those not yet visited at s; the
+            // next crossing to open is (nj, en) in first-step order.  One loop iteration = at most one sample per lane.
+            uint32_t act = 0u, cur = 0u, nj = head, en = 0u;
+            int nlo = 0x7fffffff, s = 0;
+            if (nj != kNullLink) {
+                en = s_tab[nj * kWave + lane];
+                nlo = (int)(en >> 17);
+            }
+            bool work = has && ncross > 0;
+            v2f xxy = oxy;
+            float xz = o.z;
+            while (__ballot(work) != 0ull) {
+                if (work) {
+                    if (cur == 0u) {  // step s is done: next step with an open crossing
+                        if (act == 0u && nj == kNullLink) {
+                            work = false;
                         } else {
-                            const float e1 = p.fadeexp - 1.f;
-                            ypow = mk3(fast_pow(fabsf(y.x), e1) * (y.x > 0.f ? 1.f : -1.f),
-                                       fast_pow(fabsf(y.y), e1) * (y.y > 0.f ? 1.f : -1.f),
-                                       fast_pow(fabsf(y.z), e1) * (y.z > 0.f ? 1.f : -1.f));
-                        }
-                        const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
-                        const float *Wk = p.warp + ((size_t)n * K + k) * VW3;
-                        const TriG tw = tri_general(y, p.WD, p.WH, p.WW);
-                        f3 y1 = mk3(0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            int vox;
-                            float w;
-                            if (tri_inb(tw, c, p.WD, p.WH, p.WW, vox, w)) {
-                                const float *qw = Wk + (size_t)vox * 3;
-                                y1.x += qw[0] * w, y1.y += qw[1] * w, y1.z += qw[2] * w;
-                            }
-                        }
-                        const float *Tk = T + (size_t)k * V4;
-                        const TriG tt = tri_general(y1, p.TD, p.TH, p.TW);
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            int vox;
-                            float w;
-                            if (tri_inb(tt, c, p.TD, p.TH, p.TW, vox, w)) {
-                                const float4 qv = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
-                                v.x += qv.x * w, v.y += qv.y * w, v.z += qv.z * w, v.w += qv.w * w;
-                            }
-                        }
-                        const float alpha = v.w * fade;
-                        // ---- primaccum.h:81-98 ----
-                        const float a = alpha * dt;
-                        const bool thissat = rgba.w + a >= 1.f;
-                        sat = sat || thissat;
-                        const float weight = sat ? (1.f - rgba.w) : a;
-                        float4 dLs;
-                        dLs.x = weight * dL3.x;
-                        dLs.y = weight * dL3.y;
-                        dLs.z = weight * dL3.z;
-                        dLs.w = sat ? 0.f
-                                    : dt * ((v.x - (has_sat ? rsat_in.x : 0.f)) * dL3.x +
-                                            (v.y - (has_sat ? rsat_in.y : 0.f)) * dL3.y +
-                                            (v.z - (has_sat ? rsat_in.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
-                        rgba.x += v.x * weight;
-                        rgba.y += v.y * weight;
-                        rgba.z += v.z * weight;
-                        rgba.w += weight;
-                        if (emit) {
-                            const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
-                            gy = ypow * gf;
-                            dLs.w *= fade;
-                            float *gTk = gT + (size_t)k * V4;
-                            f3 gi1 = mk3(0.f, 0.f, 0.f);
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                int vox;
-                                float w;
-                                if (tri_inb(tt, c, p.TD, p.TH, p.TW, vox, w)) {
-                                    const float4 qv = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
-                                    float *g = gTk + (size_t)vox * 4;
-                                    atomicAdd(g + 0, w * dLs.x);
-                                    atomicAdd(g + 1, w * dLs.y);
-                                    atomicAdd(g + 2, w * dLs.z);
-                                    atomicAdd(g + 3, w * dLs.w);
-                                    tri_posgrad_acc(tt, c, qv.x * dLs.x + qv.y * dLs.y + qv.z * dLs.z + qv.w * dLs.w, gi1);
+                            s = act != 0u ? s + 1 : nlo;
+                            while (nlo <= s) {  // crossings that open here (first-step order)
+                                act |= 1u << nj;
+                                nj = (en >> 6) & 31u;
+                                nlo = 0x7fffffff;
+                                if (nj != kNullLink) {
+                                    en = s_tab[nj * kWave + lane];
+                                    nlo = (int)(en >> 17);
                                 }
                             }
-                            const f3 g1 = mk3(mx * gi1.x, my * gi1.y, mz * gi1.z);  // dL/dy1
-                            float *gWk = p.grad_warp + ((size_t)n * K + k) * VW3;
-                            f3 gi0 = mk3(0.f, 0.f, 0.f);
-#pragma unroll
+                            const float t = lattice_t(s, dt, tmin);
+                            if (t < tend) {  // subset_kernel.h:84; t only grows from here
+                                cur = act;
+                                ray_point(oxy, o.z, dxy, d.z, t, xxy, xz);
+                            } else {
+                                work = false;
+                            }
+                        }
+                    }
+                    if (cur != 0u) {
+                        const int j = __ffs((int)cur) - 1;
+                        cur &= cur - 1u;
+                        const uint32_t e = s_tab[j * kWave + lane];
+                        const int slot = (int)(e & 63u);
+                        if (s >= (int)(e >> 17) + (int)((e >> 11) & 63u)) act &= ~(1u << j);  // its last step
+                        const float4 ra = s_rec[slot * 4 + 0], rb = s_rec[slot * 4 + 1], rc = s_rec[slot * 4 + 2],
+                                     rd4 = s_rec[slot * 4 + 3];
+                        RecP q;
+                        q.r0xy = v2f{ra.x, ra.y}, q.r1xy = v2f{ra.z, ra.w}, q.r2xy = v2f{rb.x, rb.y}, q.pxy = v2f{rb.z, rb.w};
+                        q.r0z = rc.x, q.r1z = rc.y, q.r2z = rc.z, q.pz = rc.w;
+                        q.sxy = v2f{rd4.x, rd4.y}, q.sz = rd4.z;
+                        const int k = __float_as_int(rd4.w);
+                        const Y3 yp = box_point(q, xxy, xz);
+                        if (s >= incs && strictly_inside(yp)) {
+                            const f3 y = mk3(yp.xy.x, yp.xy.y, yp.z);
+                            float4 v;
+                            if constexpr (TS > 0)
+                                v = sample_slab_c<FADE8, TS>(T, (uint32_t)k * (uint32_t)(TS * TS * TS * 16), y, p.fadescale,
+                                                             p.fadeexp);
+                            else
+                                v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale, p.fadeexp);
+                            float contrib;
+                            if (composite(rgba, v, dt, contrib)) {  // saturated: nothing after this sample is evaluated
+                                raysat = mk3(v.x, v.y, v.z);
+                                satkey = ((uint32_t)s << 9) | (uint32_t)slot;
+                                wbefore = rgba.w - contrib;
+                                work = false;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // step window of the packet
+            int s = uni(wave_min(incs));
+            int s_last;
+            {
+                int mylast = -1;
+                for (int j = lane; j < nh; j += kWave) mylast = max(mylast, ranges_ok ? ((s_a[j] >> 16) & 0xffff) : 0x7ffffffe);
+                s_last = uni(wave_max(mylast));
+                // no sample at or beyond t = tend: bound the sweep by the rays' own end as well
+                const int myend = has ? (int)fminf(floorf((tend - tmin) * fast_rcp(dt)) + 1.f, 1.0e9f) : -1;
+                s_last = min(s_last, uni(wave_max(myend)));
+            }
+            const int nchunks = (nh + kWave - 1) / kWave;
+            bool sat = false;
+            // list slot `lane` of chunk 0 (every packet of a head-like scene fits in it): range and entry in registers
+            const int rgc0 = lane < nh ? s_a[lane] : 0;
+            const int entc0 = lane < nh ? s_b[lane] : 0;
+
+            while (s <= s_last) {
+                if (__ballot(has && !sat) == 0ull) break;  // every ray saturated (subset_kernel.h:76)
+                const float t = lattice_t(s, dt, tmin);
+                v2f xxy;
+                float xz_;
+                ray_point(oxy, o.z, dxy, d.z, t, xxy, xz_);
+                const f3 x = mk3(xxy.x, xxy.y, xz_);
+                const bool inrange = has && s >= incs && t < tend;
+                bool anyslot = false;
+                int nextlo = 0x7fffffff;
+                for (int ch = 0; ch < nchunks; ++ch) {
+                    const int j = ch * kWave + lane;
+                    bool on = false;
+                    if (j < nh) {
+                        const int rg = ch == 0 ? rgc0 : s_a[j];
+                        const int lo = rg & 0xffff, hi = (rg >> 16) & 0xffff;
+                        on = !ranges_ok || (lo <= s && s <= hi);
+                        if (lo > s) nextlo = min(nextlo, lo);
+                    }
+                    unsigned long long m = __ballot(on);
+                    anyslot = anyslot || (m != 0ull);
+                    if (!BWD) {
+                        // Forward: (A) every active slot's inside test with the record broadcast from LDS -> per-lane
+                        // bitmask of the slots this ray is inside at this step; (B) every lane then consumes ITS OWN
+                        // slots in ascending list order, all lanes sampling at once (records gathered per lane).  On
+                        // head-like scenes the boxes active at one step cover mostly disjoint parts of the packet, so
+                        // (B) runs ~overlap-depth rounds instead of one round per active slot.
+                        unsigned long long mine = 0ull;
+                        while (m) {  // list entries of chunk 0 come from registers via v_readlane (no LDS round trip)
+                            const int bit = __ffsll((long long)m) - 1;
+                            m &= m - 1ull;
+                            const int ent = ch == 0 ? __builtin_amdgcn_readlane(entc0, bit) : uni(s_b[ch * kWave + bit]);
+                            const int slot = (ent >> 24) & 0xff;
+                            const RecP q = (slot != kNoSlot) ? recp_from_lds(s_rec, slot)
+                                                              : recp_of(rec_from_global(pp, pr, ps, ent & 0xffffff));
+                            const bool inside = inrange && !sat && strictly_inside(box_point(q, xxy, x.z));  // subset_kernel.h:84
+                            if (inside) mine |= 1ull << bit;
+                        }
+                        if (MVP_DEBUG_STAGE(p) == 3) mine = 0ull;
+                        while (__ballot(mine != 0ull) != 0ull) {
+                            if (mine != 0ull) {
+                                const int bit = __ffsll((long long)mine) - 1;
+                                mine &= mine - 1ull;
+                                const int ent = s_b[ch * kWave + bit];
+                                int k = ent & 0xffffff;
+                                const int slot = (ent >> 24) & 0xff;
+                                // Opaque on purpose: with the TS > 0 sampler below, hipcc (ROCm 7.2) dropped this mask and fed
+                                // the raw entry (slot bits included) to the 64-bit address of the record loads -> wild reads.
+                                asm volatile("; k = entry & 0xffffff" : "+v"(k));
+                                const RecP q = (slot != kNoSlot) ? recp_from_lds(s_rec, slot)
+                                                                  : recp_of(rec_from_global(pp, pr, ps, k));
+                                const Y3 yp = box_point(q, xxy, x.z);
+                                const f3 y = mk3(yp.xy.x, yp.xy.y, yp.z);
+                                float4 v;
+                                if (WARP) {  // primsampler.h:48-63 with dowarp: fade from y0, template sampled at warp(y0)
+                                    const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
+                                    const f3 y1 = warp_lookup(p.warp + ((size_t)n * K + k) * VW3, y, p.WD, p.WH, p.WW);
+                                    v = tplate_lookup_general(T + (size_t)k * V4, y1, p.TD, p.TH, p.TW);
+                                    v.w *= fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                                } else {
+                                    if constexpr (TS > 0)
+                                        v = sample_slab_c<FADE8, TS>(T, (uint32_t)k * (uint32_t)(TS * TS * TS * 16), y,
+                                                                     p.fadescale, p.fadeexp);
+                                    else
+                                        v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale,
+                                                               p.fadeexp);
+                                }
+                                float contrib;
+                                if (composite(rgba, v, dt, contrib)) {
+                                    raysat = mk3(v.x, v.y, v.z);
+                                    sat = true;
+                                    satkey = ((uint32_t)s << 9) | (uint32_t)(ch * kWave + bit);
+                                    wbefore = rgba.w - contrib;
+                                    mine = 0ull;  // saturated: nothing after this sample is evaluated
+                                }
+                            }
+                        }
+                        continue;
+                    }
+                    while (m) {
+                        const int bit = __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        const int ent = uni(s_b[ch * kWave + bit]);
+                        const int k = ent & 0xffffff, slot = (ent >> 24) & 0xff;
+                        const Rec q = (slot != kNoSlot) ? rec_from_lds(s_rec, slot) : rec_from_global(pp, pr, ps, k);
+                        const f3 xmt = x - q.pos;
+                        const f3 rxmt = rot_rows(q, xmt);
+                        const f3 y = rxmt * q.scale;
+                        const bool inside = inrange && !sat && y.x > -1.f && y.x < 1.f && y.y > -1.f && y.y < 1.f &&
+                                            y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
+                        if (__ballot(inside) == 0ull) continue;
+                        // fallback backward: only primitives the primitive-centric kernel could not own
+                        const bool emit = !BWD || emit_all || (p.pl_count[(size_t)n * K + k] > (uint32_t)p.pl_cap);
+
+                        f3 gy = mk3(0.f, 0.f, 0.f);  // BWD: dL/dy of this lane's sample (0 when not inside)
+                        if (BWD && WARP && inside) {
+                            // ---- warp-field sampler, backward (primsampler.h:68-91 with dowarp; utils.h:504-643 twice) ----
+                            const float fade = fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                            f3 ypow;
+                            if (FADE8) {
+                                const f3 y2 = y * y, y4 = y2 * y2;
+                                ypow = y4 * y2 * y;
+                            } else {
+                                const float e1 = p.fadeexp - 1.f;
+                                ypow = mk3(fast_pow(fabsf(y.x), e1) * (y.x > 0.f ? 1.f : -1.f),
+                                           fast_pow(fabsf(y.y), e1) * (y.y > 0.f ? 1.f : -1.f),
+                                           fast_pow(fabsf(y.z), e1) * (y.z > 0.f ? 1.f : -1.f));
+                            }
+                            const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
+                            const float *Wk = p.warp + ((size_t)n * K + k) * VW3;
+                            const TriG tw = tri_general(y, p.WD, p.WH, p.WW);
+                            f3 y1 = mk3(0.f, 0.f, 0.f);
+    #pragma unroll
                             for (int c = 0; c < 8; ++c) {
                                 int vox;
                                 float w;
                                 if (tri_inb(tw, c, p.WD, p.WH, p.WW, vox, w)) {
                                     const float *qw = Wk + (size_t)vox * 3;
-                                    float *g = gWk + (size_t)vox * 3;
-                                    atomicAdd(g + 0, w * g1.x);
-                                    atomicAdd(g + 1, w * g1.y);
-                                    atomicAdd(g + 2, w * g1.z);
-                                    tri_posgrad_acc(tw, c, qw[0] * g1.x + qw[1] * g1.y + qw[2] * g1.z, gi0);
+                                    y1.x += qw[0] * w, y1.y += qw[1] * w, y1.z += qw[2] * w;
                                 }
                             }
-                            gy.x += 0.5f * (float)(p.WW - 1) * gi0.x;
-                            gy.y += 0.5f * (float)(p.WH - 1) * gi0.y;
-                            gy.z += 0.5f * (float)(p.WD - 1) * gi0.z;
-                        }
-                    } else if (inside) {
-                        // ---- fade (primsampler.h:48-51) ----
-                        float fade;
-                        f3 ypow;  // |y|^(fadeexp-1) * sgn(y), backward only
-                        if (FADE8) {
-                            const f3 y2 = y * y, y4 = y2 * y2;
-                            fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
-                            if (BWD) ypow = y4 * y2 * y;
-                        } else {
-                            const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
-                            fade = fast_exp(-p.fadescale * (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) +
-                                                            fast_pow(ay.z, p.fadeexp)));
-                            if (BWD) {
-                                const float e1 = p.fadeexp - 1.f;
-                                ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f),
-                                           fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
-                                           fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
+                            const float *Tk = T + (size_t)k * V4;
+                            const TriG tt = tri_general(y1, p.TD, p.TH, p.TW);
+                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    #pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                int vox;
+                                float w;
+                                if (tri_inb(tt, c, p.TD, p.TH, p.TW, vox, w)) {
+                                    const float4 qv = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
+                                    v.x += qv.x * w, v.y += qv.y * w, v.z += qv.z * w, v.w += qv.w * w;
+                                }
                             }
-                        }
-                        // ---- trilinear, align_corners=True (utils.h:414-468).  y strictly inside (-1,1) puts
-                        //      i in [0, T-1]; clamping the base corner to T-2 keeps all 8 corners in bounds and
-                        //      gives the same value as the reference's zero-padded form (the weight of an
-                        //      out-of-bounds corner is exactly 0 there).
-                        const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
-                        const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
-                        const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
-                        const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
-                                  z0 = min((int)floorf(iz), p.TD - 2);
-                        const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
-                        const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
-                        const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
-                        const size_t vbase = (size_t)k * V4 + (size_t)z0 * sD + (size_t)y0 * sH + (size_t)x0 * sW;
-                        const float *Tp = T + vbase;
-                        const float4 c000 = *reinterpret_cast<const float4 *>(Tp);
-                        const float4 c001 = *reinterpret_cast<const float4 *>(Tp + sW);
-                        const float4 c010 = *reinterpret_cast<const float4 *>(Tp + sH);
-                        const float4 c011 = *reinterpret_cast<const float4 *>(Tp + sH + sW);
-                        const float4 c100 = *reinterpret_cast<const float4 *>(Tp + sD);
-                        const float4 c101 = *reinterpret_cast<const float4 *>(Tp + sD + sW);
-                        const float4 c110 = *reinterpret_cast<const float4 *>(Tp + sD + sH);
-                        const float4 c111 = *reinterpret_cast<const float4 *>(Tp + sD + sH + sW);
-                        const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
-                                    w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
-                                    w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
-                        float4 v;
-                        v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 +
-                              c101.x * w101 + c110.x * w110 + c111.x * w111;
-                        v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 +
-                              c101.y * w101 + c110.y * w110 + c111.y * w111;
-                        v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 +
-                              c101.z * w101 + c110.z * w110 + c111.z * w111;
-                        v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 +
-                              c101.w * w101 + c110.w * w110 + c111.w * w111;
-                        const float alpha = v.w * fade;  // primsampler.h:63
-
-                        {  // (only the backward instantiation reaches this body; the forward left through pass B above)
+                            const float alpha = v.w * fade;
                             // ---- primaccum.h:81-98 ----
                             const float a = alpha * dt;
                             const bool thissat = rgba.w + a >= 1.f;
@@ -965,93 +1133,207 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             rgba.z += v.z * weight;
                             rgba.w += weight;
                             if (emit) {
-                            // ---- primsampler.h:70-76 ----
-                            const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
-                            gy = ypow * gf;
-                            dLs.w *= fade;
-                            // ---- utils.h:582-589: scatter w_c * dL to the 8 corners (32 fp32 atomics) ----
-                            float *Gp = gT + vbase;
-#define MVP_SCATTER(OFF_, WGT_)                           \
-    atomicAdd(Gp + (OFF_) + 0, (WGT_) * dLs.x);           \
-    atomicAdd(Gp + (OFF_) + 1, (WGT_) * dLs.y);           \
-    atomicAdd(Gp + (OFF_) + 2, (WGT_) * dLs.z);           \
-    atomicAdd(Gp + (OFF_) + 3, (WGT_) * dLs.w);
-                            MVP_SCATTER(0, w000)
-                            MVP_SCATTER(sW, w001)
-                            MVP_SCATTER(sH, w010)
-                            MVP_SCATTER(sH + sW, w011)
-                            MVP_SCATTER(sD, w100)
-                            MVP_SCATTER(sD + sW, w101)
-                            MVP_SCATTER(sD + sH, w110)
-                            MVP_SCATTER(sD + sH + sW, w111)
-#undef MVP_SCATTER
-                            // ---- utils.h:592-642: d/d(position) ----
-#define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
-                            const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
-                                        d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
-                                        d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
-#undef MVP_DOT4
-                            const float gix = wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) +
-                                              wy0 * wz1 * (d101 - d100) + wy1 * wz1 * (d111 - d110);
-                            const float giy = wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) +
-                                              wx0 * wz1 * (d110 - d100) + wx1 * wz1 * (d111 - d101);
-                            const float giz = wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) +
-                                              wx0 * wy1 * (d110 - d010) + wx1 * wy1 * (d111 - d011);
-                            gy.x += mx * gix;
-                            gy.y += my * giy;
-                            gy.z += mz * giz;
-                            }  // emit
+                                const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                                gy = ypow * gf;
+                                dLs.w *= fade;
+                                float *gTk = gT + (size_t)k * V4;
+                                f3 gi1 = mk3(0.f, 0.f, 0.f);
+    #pragma unroll
+                                for (int c = 0; c < 8; ++c) {
+                                    int vox;
+                                    float w;
+                                    if (tri_inb(tt, c, p.TD, p.TH, p.TW, vox, w)) {
+                                        const float4 qv = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
+                                        float *g = gTk + (size_t)vox * 4;
+                                        atomicAdd(g + 0, w * dLs.x);
+                                        atomicAdd(g + 1, w * dLs.y);
+                                        atomicAdd(g + 2, w * dLs.z);
+                                        atomicAdd(g + 3, w * dLs.w);
+                                        tri_posgrad_acc(tt, c, qv.x * dLs.x + qv.y * dLs.y + qv.z * dLs.z + qv.w * dLs.w, gi1);
+                                    }
+                                }
+                                const f3 g1 = mk3(mx * gi1.x, my * gi1.y, mz * gi1.z);  // dL/dy1
+                                float *gWk = p.grad_warp + ((size_t)n * K + k) * VW3;
+                                f3 gi0 = mk3(0.f, 0.f, 0.f);
+    #pragma unroll
+                                for (int c = 0; c < 8; ++c) {
+                                    int vox;
+                                    float w;
+                                    if (tri_inb(tw, c, p.WD, p.WH, p.WW, vox, w)) {
+                                        const float *qw = Wk + (size_t)vox * 3;
+                                        float *g = gWk + (size_t)vox * 3;
+                                        atomicAdd(g + 0, w * g1.x);
+                                        atomicAdd(g + 1, w * g1.y);
+                                        atomicAdd(g + 2, w * g1.z);
+                                        tri_posgrad_acc(tw, c, qw[0] * g1.x + qw[1] * g1.y + qw[2] * g1.z, gi0);
+                                    }
+                                }
+                                gy.x += 0.5f * (float)(p.WW - 1) * gi0.x;
+                                gy.y += 0.5f * (float)(p.WH - 1) * gi0.y;
+                                gy.z += 0.5f * (float)(p.WD - 1) * gi0.z;
+                            }
+                        } else if (inside) {
+                            // ---- fade (primsampler.h:48-51) ----
+                            float fade;
+                            f3 ypow;  // |y|^(fadeexp-1) * sgn(y), backward only
+                            if (FADE8) {
+                                const f3 y2 = y * y, y4 = y2 * y2;
+                                fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+                                if (BWD) ypow = y4 * y2 * y;
+                            } else {
+                                const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
+                                fade = fast_exp(-p.fadescale * (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) +
+                                                                fast_pow(ay.z, p.fadeexp)));
+                                if (BWD) {
+                                    const float e1 = p.fadeexp - 1.f;
+                                    ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f),
+                                               fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
+                                               fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
+                                }
+                            }
+                            // ---- trilinear, align_corners=True (utils.h:414-468).  y strictly inside (-1,1) puts
+                            //      i in [0, T-1]; clamping the base corner to T-2 keeps all 8 corners in bounds and
+                            //      gives the same value as the reference's zero-padded form (the weight of an
+                            //      out-of-bounds corner is exactly 0 there).
+                            const float ix = (y.x + 1.f) * 0.5f * (float)(p.TW - 1);
+                            const float iy = (y.y + 1.f) * 0.5f * (float)(p.TH - 1);
+                            const float iz = (y.z + 1.f) * 0.5f * (float)(p.TD - 1);
+                            const int x0 = min((int)floorf(ix), p.TW - 2), y0 = min((int)floorf(iy), p.TH - 2),
+                                      z0 = min((int)floorf(iz), p.TD - 2);
+                            const float wx1 = ix - (float)x0, wx0 = (float)(x0 + 1) - ix;
+                            const float wy1 = iy - (float)y0, wy0 = (float)(y0 + 1) - iy;
+                            const float wz1 = iz - (float)z0, wz0 = (float)(z0 + 1) - iz;
+                            const size_t vbase = (size_t)k * V4 + (size_t)z0 * sD + (size_t)y0 * sH + (size_t)x0 * sW;
+                            const float *Tp = T + vbase;
+                            const float4 c000 = *reinterpret_cast<const float4 *>(Tp);
+                            const float4 c001 = *reinterpret_cast<const float4 *>(Tp + sW);
+                            const float4 c010 = *reinterpret_cast<const float4 *>(Tp + sH);
+                            const float4 c011 = *reinterpret_cast<const float4 *>(Tp + sH + sW);
+                            const float4 c100 = *reinterpret_cast<const float4 *>(Tp + sD);
+                            const float4 c101 = *reinterpret_cast<const float4 *>(Tp + sD + sW);
+                            const float4 c110 = *reinterpret_cast<const float4 *>(Tp + sD + sH);
+                            const float4 c111 = *reinterpret_cast<const float4 *>(Tp + sD + sH + sW);
+                            const float w000 = wx0 * wy0 * wz0, w001 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0,
+                                        w011 = wx1 * wy1 * wz0, w100 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1,
+                                        w110 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+                            float4 v;
+                            v.x = c000.x * w000 + c001.x * w001 + c010.x * w010 + c011.x * w011 + c100.x * w100 +
+                                  c101.x * w101 + c110.x * w110 + c111.x * w111;
+                            v.y = c000.y * w000 + c001.y * w001 + c010.y * w010 + c011.y * w011 + c100.y * w100 +
+                                  c101.y * w101 + c110.y * w110 + c111.y * w111;
+                            v.z = c000.z * w000 + c001.z * w001 + c010.z * w010 + c011.z * w011 + c100.z * w100 +
+                                  c101.z * w101 + c110.z * w110 + c111.z * w111;
+                            v.w = c000.w * w000 + c001.w * w001 + c010.w * w010 + c011.w * w011 + c100.w * w100 +
+                                  c101.w * w101 + c110.w * w110 + c111.w * w111;
+                            const float alpha = v.w * fade;  // primsampler.h:63
+
+                            {  // (only the backward instantiation reaches this body; the forward left through pass B above)
+                                // ---- primaccum.h:81-98 ----
+                                const float a = alpha * dt;
+                                const bool thissat = rgba.w + a >= 1.f;
+                                sat = sat || thissat;
+                                const float weight = sat ? (1.f - rgba.w) : a;
+                                float4 dLs;
+                                dLs.x = weight * dL3.x;
+                                dLs.y = weight * dL3.y;
+                                dLs.z = weight * dL3.z;
+                                dLs.w = sat ? 0.f
+                                            : dt * ((v.x - (has_sat ? rsat_in.x : 0.f)) * dL3.x +
+                                                    (v.y - (has_sat ? rsat_in.y : 0.f)) * dL3.y +
+                                                    (v.z - (has_sat ? rsat_in.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
+                                rgba.x += v.x * weight;
+                                rgba.y += v.y * weight;
+                                rgba.z += v.z * weight;
+                                rgba.w += weight;
+                                if (emit) {
+                                // ---- primsampler.h:70-76 ----
+                                const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                                gy = ypow * gf;
+                                dLs.w *= fade;
+                                // ---- utils.h:582-589: scatter w_c * dL to the 8 corners (32 fp32 atomics) ----
+                                float *Gp = gT + vbase;
+    #define MVP_SCATTER(OFF_, WGT_)                           \
+        atomicAdd(Gp + (OFF_) + 0, (WGT_) * dLs.x);           \
+        atomicAdd(Gp + (OFF_) + 1, (WGT_) * dLs.y);           \
+        atomicAdd(Gp + (OFF_) + 2, (WGT_) * dLs.z);           \
+        atomicAdd(Gp + (OFF_) + 3, (WGT_) * dLs.w);
+                                MVP_SCATTER(0, w000)
+                                MVP_SCATTER(sW, w001)
+                                MVP_SCATTER(sH, w010)
+                                MVP_SCATTER(sH + sW, w011)
+                                MVP_SCATTER(sD, w100)
+                                MVP_SCATTER(sD + sW, w101)
+                                MVP_SCATTER(sD + sH, w110)
+                                MVP_SCATTER(sD + sH + sW, w111)
+    #undef MVP_SCATTER
+                                // ---- utils.h:592-642: d/d(position) ----
+    #define MVP_DOT4(C_) ((C_).x * dLs.x + (C_).y * dLs.y + (C_).z * dLs.z + (C_).w * dLs.w)
+                                const float d000 = MVP_DOT4(c000), d001 = MVP_DOT4(c001), d010 = MVP_DOT4(c010),
+                                            d011 = MVP_DOT4(c011), d100 = MVP_DOT4(c100), d101 = MVP_DOT4(c101),
+                                            d110 = MVP_DOT4(c110), d111 = MVP_DOT4(c111);
+    #undef MVP_DOT4
+                                const float gix = wy0 * wz0 * (d001 - d000) + wy1 * wz0 * (d011 - d010) +
+                                                  wy0 * wz1 * (d101 - d100) + wy1 * wz1 * (d111 - d110);
+                                const float giy = wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) +
+                                                  wx0 * wz1 * (d110 - d100) + wx1 * wz1 * (d111 - d101);
+                                const float giz = wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) +
+                                                  wx0 * wy1 * (d110 - d010) + wx1 * wy1 * (d111 - d011);
+                                gy.x += mx * gix;
+                                gy.y += my * giy;
+                                gy.z += mz * giz;
+                                }  // emit
+                            }
                         }
-                    }
-                    if (BWD && emit) {
-                        // ---- primtransf.h:155-179.  grad_scale_j = sum rxmt_j*gy_j, grad_R[i][j] = s_j * sum xmt_i*gy_j,
-                        //      grad_pos_i = -sum_j R[i][j]*s_j * sum gy_j: 12 wave sums, then 15 lanes flush. ----
-                        // lanes without a sample contribute exact zeros (their x may be inf/NaN: rays outside the image)
-                        const f3 xm = inside ? xmt : mk3(0.f, 0.f, 0.f);
-                        const float a0 = uni(wave_sum(gy.x)), a1 = uni(wave_sum(gy.y)), a2 = uni(wave_sum(gy.z));
-                        const float c00 = uni(wave_sum(xm.x * gy.x)), c01 = uni(wave_sum(xm.x * gy.y)),
-                                    c02 = uni(wave_sum(xm.x * gy.z));
-                        const float c10 = uni(wave_sum(xm.y * gy.x)), c11 = uni(wave_sum(xm.y * gy.y)),
-                                    c12 = uni(wave_sum(xm.y * gy.z));
-                        const float c20 = uni(wave_sum(xm.z * gy.x)), c21 = uni(wave_sum(xm.z * gy.y)),
-                                    c22 = uni(wave_sum(xm.z * gy.z));
-                        float val = 0.f;
-                        float *dst = nullptr;
-                        const f3 sa = mk3(q.scale.x * a0, q.scale.y * a1, q.scale.z * a2);
-                        switch (lane) {
-                            case 0: val = q.scale.x * c00; break;
-                            case 1: val = q.scale.y * c01; break;
-                            case 2: val = q.scale.z * c02; break;
-                            case 3: val = q.scale.x * c10; break;
-                            case 4: val = q.scale.y * c11; break;
-                            case 5: val = q.scale.z * c12; break;
-                            case 6: val = q.scale.x * c20; break;
-                            case 7: val = q.scale.y * c21; break;
-                            case 8: val = q.scale.z * c22; break;
-                            case 9: val = q.r0.x * c00 + q.r1.x * c10 + q.r2.x * c20; break;   // sum rxmt_x * gy_x
-                            case 10: val = q.r0.y * c01 + q.r1.y * c11 + q.r2.y * c21; break;
-                            case 11: val = q.r0.z * c02 + q.r1.z * c12 + q.r2.z * c22; break;
-                            case 12: val = -dot3(q.r0, sa); break;
-                            case 13: val = -dot3(q.r1, sa); break;
-                            case 14: val = -dot3(q.r2, sa); break;
-                            default: break;
+                        if (BWD && emit) {
+                            // ---- primtransf.h:155-179.  grad_scale_j = sum rxmt_j*gy_j, grad_R[i][j] = s_j * sum xmt_i*gy_j,
+                            //      grad_pos_i = -sum_j R[i][j]*s_j * sum gy_j: 12 wave sums, then 15 lanes flush. ----
+                            // lanes without a sample contribute exact zeros (their x may be inf/NaN: rays outside the image)
+                            const f3 xm = inside ? xmt : mk3(0.f, 0.f, 0.f);
+                            const float a0 = uni(wave_sum(gy.x)), a1 = uni(wave_sum(gy.y)), a2 = uni(wave_sum(gy.z));
+                            const float c00 = uni(wave_sum(xm.x * gy.x)), c01 = uni(wave_sum(xm.x * gy.y)),
+                                        c02 = uni(wave_sum(xm.x * gy.z));
+                            const float c10 = uni(wave_sum(xm.y * gy.x)), c11 = uni(wave_sum(xm.y * gy.y)),
+                                        c12 = uni(wave_sum(xm.y * gy.z));
+                            const float c20 = uni(wave_sum(xm.z * gy.x)), c21 = uni(wave_sum(xm.z * gy.y)),
+                                        c22 = uni(wave_sum(xm.z * gy.z));
+                            float val = 0.f;
+                            float *dst = nullptr;
+                            const f3 sa = mk3(q.scale.x * a0, q.scale.y * a1, q.scale.z * a2);
+                            switch (lane) {
+                                case 0: val = q.scale.x * c00; break;
+                                case 1: val = q.scale.y * c01; break;
+                                case 2: val = q.scale.z * c02; break;
+                                case 3: val = q.scale.x * c10; break;
+                                case 4: val = q.scale.y * c11; break;
+                                case 5: val = q.scale.z * c12; break;
+                                case 6: val = q.scale.x * c20; break;
+                                case 7: val = q.scale.y * c21; break;
+                                case 8: val = q.scale.z * c22; break;
+                                case 9: val = q.r0.x * c00 + q.r1.x * c10 + q.r2.x * c20; break;   // sum rxmt_x * gy_x
+                                case 10: val = q.r0.y * c01 + q.r1.y * c11 + q.r2.y * c21; break;
+                                case 11: val = q.r0.z * c02 + q.r1.z * c12 + q.r2.z * c22; break;
+                                case 12: val = -dot3(q.r0, sa); break;
+                                case 13: val = -dot3(q.r1, sa); break;
+                                case 14: val = -dot3(q.r2, sa); break;
+                                default: break;
+                            }
+                            if (lane < 9)
+                                dst = p.grad_primrot + ((size_t)n * K + k) * 9 + lane;
+                            else if (lane < 12)
+                                dst = p.grad_primscale + ((size_t)n * K + k) * 3 + (lane - 9);
+                            else if (lane < 15)
+                                dst = p.grad_primpos + ((size_t)n * K + k) * 3 + (lane - 12);
+                            if (dst) atomicAdd(dst, val);
                         }
-                        if (lane < 9)
-                            dst = p.grad_primrot + ((size_t)n * K + k) * 9 + lane;
-                        else if (lane < 12)
-                            dst = p.grad_primscale + ((size_t)n * K + k) * 3 + (lane - 9);
-                        else if (lane < 15)
-                            dst = p.grad_primpos + ((size_t)n * K + k) * 3 + (lane - 12);
-                        if (dst) atomicAdd(dst, val);
                     }
                 }
-            }
-            if (anyslot) {
-                ++s;
-            } else {  // nothing listed covers this step: jump to the next range start
-                const int nx = uni(wave_min(nextlo));
-                if (nx == 0x7fffffff) break;
-                s = nx;
+                if (anyslot) {
+                    ++s;
+                } else {  // nothing listed covers this step: jump to the next range start
+                    const int nx = uni(wave_min(nextlo));
+                    if (nx == 0x7fffffff) break;
+                    s = nx;
+                }
             }
         }
     }
@@ -1081,9 +1363,15 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
 // TS > 0 (forward, no warp field): TS^3 slabs with compile-time strides, see sample_slab_c
 template <bool BWD, bool FADE8, bool WARP, int TS = 0>
 __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
-    __shared__ int s_a[kMaxList];
-    __shared__ int s_b[kMaxList];
-    __shared__ float4 s_rec[kRecSlots * 4];
+    // One LDS block per wave: [SRT records: 64 x 64 B][region].  The region is the two 512-entry frontier / list arrays
+    // (s_a, s_b); in the plain forward it is large enough to be re-used, after the traversal, as the per-ray crossing
+    // table of the lane-independent sweep (kFastCross rows x 64 lanes x 4 B).
+    constexpr int kRegion = (!BWD && !WARP && kFastCross * kWave > 2 * kMaxList) ? kFastCross * kWave : 2 * kMaxList;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[kRecSlots * 16 + kRegion];
+    float4 *s_rec = reinterpret_cast<float4 *>(smem);
+    int *s_a = reinterpret_cast<int *>(smem + kRecSlots * 16);
+    int *s_b = s_a + kMaxList;
+    uint32_t *s_tab = smem + kRecSlots * 16;
     if (BWD) {
         bool emit_all = p.fallback_all != 0;
         if (!emit_all) {  // nothing to do unless the forward raised a flag
@@ -1092,11 +1380,11 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
             emit_all = (flags & kFlagGlobal) != 0u;
         }
         for (int b = blockIdx.x; b < p.total_packets; b += gridDim.x) {
-            march_packet<BWD, FADE8, WARP, TS>(p, b, s_a, s_b, s_rec, emit_all);
+            march_packet<BWD, FADE8, WARP, TS>(p, b, s_a, s_b, s_rec, s_tab, emit_all);
             __syncthreads();
         }
     } else {
-        march_packet<BWD, FADE8, WARP, TS>(p, blockIdx.x, s_a, s_b, s_rec, true);
+        march_packet<BWD, FADE8, WARP, TS>(p, blockIdx.x, s_a, s_b, s_rec, s_tab, true);
     }
 }
 
@@ -1123,7 +1411,10 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // point with integer LDS atomics: t = int(value * 2^e * 2^16); hi += t >> 16; lo += t, wrapping (two int32
 // accumulators per slab float; fix_value() below puts them back together).  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed
 // bound B of any single contribution (|value * 2^e| < 2^14), so sums of up to 65536 contributions cannot
-// overflow; the resolution is 2^-30 * B.  Sums are exact integers => the slab gradient is bit-reproducible run
+// overflow; the resolution is 2^-30 * B, values are rounded to nearest.  B comes from the upstream gradients of the ray
+// packets on THIS primitive's list (packetmax_kernel), the slab's own max |rgb| and max |raysat|; it assumes sample
+// weights |alpha*fade*dt| <= 1 and |1 - alpha_before| <= 1 (true for non-negative opacity) -- a sample that breaks
+// that is detected and the primitive is handed to the ray-centric kernel.  Sums are exact integers => the slab gradient is bit-reproducible run
 // to run (the fp32-atomic formulation is not).  The exact number of samples each round can add is counted while
 // the rays are queued; before the running total could pass 65536 the integer sums are drained into a float array
 // in LDS (plain adds by the owning threads) and restart from zero, so any number of samples per primitive is fine.
@@ -1149,34 +1440,50 @@ constexpr int kEntriesPerRound = 4 * kEntriesPerWave;  // typical lists (~10 ent
 constexpr int kQueueCap = kEntriesPerRound * 64;       // rays per round
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
 
-// G = max |grad_rayrgba| -> out[0] (float bits; non-negative floats order like uints).  max |raysat| (out[1]) is
-// produced by the forward kernel itself.
-__global__ __launch_bounds__(256) void absmax_kernel(const float4 *__restrict__ g4, size_t n4,
-                                                     uint32_t *__restrict__ out) {
-    float m0 = 0.f;
+// Backward prologue.  (1) Per ray packet (8x8 pixels): max |grad_rayrgba| -> pmax[packet] as float bits (non-negative
+// floats order like uints; a NaN's pattern is larger than Inf's, so it is sticky).  The primitive-centric kernel
+// derives each primitive's fixed-point scale from the packets on ITS list, so one outlier pixel costs resolution
+// only in the primitives it touches.  (2) Undo what an earlier backward over the same forward left in the hand-off
+// buffer (retain_graph / several losses): the "handed over" bit of the counters and flag.
+__global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict__ g4, int N, int H, int W, int tiles_x,
+                                                        int tiles_y, uint32_t *__restrict__ pmax,
+                                                        uint32_t *__restrict__ counts, size_t ncounts,
+                                                        uint32_t *__restrict__ tail) {
+    const int lane = lane_id();
+    const size_t nwaves = (size_t)gridDim.x * (blockDim.x / kWave);
+    const size_t w0 = (size_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const size_t T = (size_t)tiles_x * tiles_y;
+    for (size_t pk = w0; pk < (size_t)N * T; pk += nwaves) {
+        const size_t n = pk / T;
+        const int tidx = (int)(pk - n * T);
+        const int ty = tidx / tiles_x, tx = tidx - ty * tiles_x;
+        const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
+        uint32_t mi = 0u;
+        if (px < W && py < H) {
+            const float4 v = g4[(n * H + py) * W + px];
+            mi = max(max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu),
+                     max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+        }
+        mi = (uint32_t)wave_max((int)mi);  // all patterns are < 2^31: signed max is the same order
+        if (lane == 0) pmax[pk] = mi;
+    }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // max(|v|) through the integer pipe: |v| as uint orders like the float for every non-NaN, and a NaN's pattern
-    // (> 0x7f800000) is larger than Inf's, so it is sticky by itself.  Four independent 16-byte loads in flight.
-    uint32_t mi = 0u;
-#define MVP_ABS4(V_)                                                                                          \
-    mi = max(max(mi, __float_as_uint((V_).x) & 0x7fffffffu),                                                  \
-             max(max(__float_as_uint((V_).y) & 0x7fffffffu, __float_as_uint((V_).z) & 0x7fffffffu),            \
-                 __float_as_uint((V_).w) & 0x7fffffffu));
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
-        MVP_ABS4(a) MVP_ABS4(b) MVP_ABS4(c) MVP_ABS4(d)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncounts; i += stride) {
+        const uint32_t c = counts[i];
+        if (c & kCountDead) counts[i] = c & ~kCountDead;
     }
-    for (; i < n4; i += stride) {
-        const float4 a = g4[i];
-        MVP_ABS4(a)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t f = tail[0];
+        if (f & kFlagBwdHandoff) tail[0] = f & ~kFlagBwdHandoff;
     }
-#undef MVP_ABS4
-    m0 = mi > 0x7f800000u ? INFINITY : __uint_as_float(mi);  // NaN -> Inf: the backward hands such a launch over
-    m0 = wave_max(m0);
-    // one same-address atomic per wave would serialise in L2 (~10 ns each, 8192 waves): only a wave that can raise the
-    // word touches it (a stale read is fine, the value is monotone)
-    if (lane_id() == 0 && __float_as_uint(m0) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_uint(m0));
+}
+
+// float -> int, round to nearest (ties up): v_cvt_rpi_i32_f32.  (int)x truncates toward zero, a systematic shrink of
+// every contribution by half a unit on average.
+__device__ __forceinline__ int fix_rn(float v) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
 
 // largest power of two s with B * s < 2^kFixHiBits (B finite, normal, > 0)
@@ -1221,7 +1528,8 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     const int k = xcd * chunkk + (i - n * chunkk);
     if (k >= K) return;
     const size_t pk = (size_t)n * K + k;
-    uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] bits(G), [2] bits(Rmax)
+    uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] reserved, [2] bits(Rmax); then per-packet bits(max |g|)
+    const uint32_t *pmax_n = tail + 3 + (size_t)n * p.tiles_x * p.tiles_y;
 
     // Everything this workgroup needs first is requested at once, before any of it is looked at: flags, list length,
     // the primitive's transform (scalar loads: wave-uniform addresses, data no kernel in flight writes) and -- for the
@@ -1244,9 +1552,11 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
 
-    // ---- stage the slab and its max |rgb| ----
+    // ---- stage the slab and its max |rgb|; bound of the upstream gradient over the packets on the list ----
     float tmax = 0.f;
+    uint32_t gbits = 0u;
     if (!dead && cnt > 0u) {
+        for (uint32_t e = tid; e < cnt; e += kPrimBlock) gbits = max(gbits, pmax_n[list[e].x >> 9]);
         if (TS == 8) {
             s_T[tid] = tv0, s_T[tid + kPrimBlock] = tv1;
             tmax = fmaxf(fmaxf(fmaxf(fabsf(tv0.x), fabsf(tv0.y)), fabsf(tv0.z)),
@@ -1267,22 +1577,26 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             for (int v = (nz4 << 2) + tid; v < 8 * Vp; v += kPrimBlock) s_hi[v] = 0;
         }
         tmax = wave_max(tmax);
-        if (lane == 0) s_red[wave] = tmax;
+        gbits = (uint32_t)wave_max((int)gbits);
+        if (lane == 0) s_red[wave] = tmax, s_red[4 + wave] = __uint_as_float(gbits);
     }
     __syncthreads();
     float s_rgb = 0.f, s_a = 0.f;
     if (!dead && cnt > 0u) {
         tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        const float G = __uint_as_float(cload(tail + 1)), Rmax = __uint_as_float(cload(tail + 2));
+        gbits = max(max(__float_as_uint(s_red[4]), __float_as_uint(s_red[5])),
+                    max(__float_as_uint(s_red[6]), __float_as_uint(s_red[7])));
+        const float G = gbits > 0x7f800000u ? INFINITY : __uint_as_float(gbits);  // NaN -> Inf -> handed over below
+        const float Rmax = __uint_as_float(cload(tail + 2));
         // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
         const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
         if (G == 0.f) {
-            s_rgb = s_a = -1.f;  // all-zero upstream gradient: outputs are zero
+            s_rgb = s_a = -1.f;  // all-zero upstream gradient on every listed packet: outputs are zero
         } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f)) {
             dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
             if (tid == 0) {
-                p.pl_count[pk] = 0xffffffffu;
-                raise_flag(tail, kFlagListOverflow);
+                atomicOr(p.pl_count + pk, kCountDead);
+                raise_flag(tail, kFlagBwdHandoff);
             }
         } else {
             s_rgb = fix_scale(Brgb) * 65536.f;  // value -> int(value * s): 16 fractional bits
@@ -1314,6 +1628,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     uint32_t ex_groups = 0u, ex_addr = 0u, ex_lanes = 0u, ex_bank[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
 #endif
     if (tid == 0) s_qn[2] = 0u;
+    bool wbad = false;      // some sample weight was outside [-1, 1]: the integer sums cannot be trusted
     uint32_t pending = 0u;  // samples accumulated into the integer arrays since the last drain (workgroup-uniform)
     bool drained = false;   // the float drain target holds data (workgroup-uniform)
     for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
@@ -1389,12 +1704,13 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             if (lane == 0 && wl > 0.f) atomicAdd(s_qn + 1, (uint32_t)wl);
         }
         __syncthreads();
-        // a ray crosses this box over more than 127 steps, or the round alone would add more samples than the integer
-        // accumulators can take between two drains: not this kernel's case
+        // a ray crosses this box over more than 127 steps, a sample weight left [-1, 1] in an earlier round (signed
+        // opacity), or the round alone would add more samples than the integer accumulators can take between two
+        // drains: not this kernel's case
         if (s_qn[2] != 0u || s_qn[1] > kFixMaxSamples) {
             if (tid == 0) {
-                p.pl_count[pk] = 0xffffffffu;
-                raise_flag(tail, kFlagListOverflow);
+                atomicOr(p.pl_count + pk, kCountDead);
+                raise_flag(tail, kFlagBwdHandoff);
             }
             // (addresses re-derived from a laundered pk: this exit sits inside the march loop and would otherwise keep
             //  the output pointers of the zero-fill live -- and spilled -- through the whole loop)
@@ -1578,6 +1894,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     const float alpha = v.w * fade;
                     const bool issat = key == satkey;
                     const float weight = issat ? (1.f - wbefore) : alpha * dt;
+                    wbad = wbad || !(fabsf(weight) <= 1.0f);  // outside the fixed-point bound (signed opacity) or NaN
                     float4 dLs;
                     dLs.x = weight * dL3.x;
                     dLs.y = weight * dL3.y;
@@ -1625,13 +1942,13 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
 #if MVP_EXP == 2
 #define MVP_FIX1(OFF_, VAL_)                                        \
     {                                                               \
-        const int t_ = (int)(VAL_);                                 \
+        const int t_ = fix_rn(VAL_);                                \
         exp_sink ^= (t_ >> 16) + (int)(OFF_);                       \
     }
 #else
 #define MVP_FIX1(OFF_, VAL_)                                        \
     {                                                               \
-        const int t_ = (int)(VAL_);                                 \
+        const int t_ = fix_rn(VAL_);                                \
         atomicAdd(Hp + (OFF_), t_ >> 16);                           \
         atomicAdd(Lp + (OFF_), (uint32_t)t_);                       \
     }
@@ -1689,6 +2006,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
 #pragma unroll
             for (int j = 0; j < 12; ++j) s_red[wave * 12 + j] = sums[j];
         }
+        if (__ballot(wbad) != 0ull && lane == 0) atomicOr(s_qn + 2, 2u);
     }
     __syncthreads();
     // The output addresses below depend only on (n, k, tid); left alone, the compiler computes them at kernel entry
@@ -1699,6 +2017,17 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     int tl = tid;
     asm volatile("; late address base" : "+s"(pkl), "+v"(tl));
     float4 *gT4l = reinterpret_cast<float4 *>(p.grad_tplate) + pkl * (size_t)V;
+    if (s_qn[2] != 0u) {  // a weight left [-1, 1] in the last round: the ray-centric kernel (fp32 atomics) owns it
+        if (tl == 0) {
+            atomicOr(p.pl_count + pkl, kCountDead);
+            raise_flag(p.pl_count + (size_t)p.N * K, kFlagBwdHandoff);
+        }
+        for (int v = tl; v < V; v += kPrimBlock) gT4l[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl < 9) p.grad_primrot[pkl * 9 + tl] = 0.f;
+        if (tl < 3) p.grad_primscale[pkl * 3 + tl] = 0.f;
+        if (tl < 3) p.grad_primpos[pkl * 3 + tl] = 0.f;
+        return;
+    }
     {  // the slab gradient, written exactly once: (hi * 2^16 + lo) / scale
         const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
         for (int v = tl; v < V; v += kPrimBlock) {
@@ -1745,9 +2074,16 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
         return MVP_ERR_BADARG;
     if (p.K > 0 && (p.TD < 2 || p.TH < 2 || p.TW < 2)) return MVP_ERR_UNSUPPORTED;
     if (p.K >= (1 << 24)) return MVP_ERR_UNSUPPORTED;  // list entries pack k into 24 bits
-    if (!p.raypos || !p.raydir || !p.tminmax) return MVP_ERR_BADARG;
+    if (p.campos) {
+        if (bwd || p.raypos || p.raydir || p.tminmax) return MVP_ERR_BADARG;
+        if (!p.camrot || !p.focal || !p.princpt) return MVP_ERR_BADARG;
+        if (!(p.volradius > 0.f) || !(p.volradius < INFINITY)) return MVP_ERR_BADARG;
+        if (p.pixelcoords && ((uintptr_t)p.pixelcoords & 7u)) return MVP_ERR_BADARG;
+    } else if (!p.raypos || !p.raydir || !p.tminmax) {
+        return MVP_ERR_BADARG;
+    }
     if (p.K > 0 && (!p.nodeaabb || !p.primpos || !p.primrot || !p.primscale || !p.tplate)) return MVP_ERR_BADARG;
-    if (!aligned16(p.tplate) || !aligned16(p.tminmax) || !aligned16(p.nodeaabb)) return MVP_ERR_BADARG;
+    if (!aligned16(p.tplate) || (p.tminmax && !aligned16(p.tminmax)) || !aligned16(p.nodeaabb)) return MVP_ERR_BADARG;
     if (p.pl_cap < 0) return MVP_ERR_BADARG;
     if (p.rayaux && !aligned16(p.rayaux)) return MVP_ERR_BADARG;
     if (p.pl_list && !aligned16(p.pl_list)) return MVP_ERR_BADARG;
@@ -1758,24 +2094,37 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     const long long blocks = 8ll * p.chunk * p.N;
     if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
     p.total_packets = (int)blocks;
+#ifdef MVP_DEBUG_HOOKS
     {
         const char *e = getenv("MVP_DEBUG_FORCE_DFS");
         p.debug_force_dfs = (e && e[0] == '1') ? 1 : 0;
+        const char *f = getenv("MVP_DEBUG_SLOT_SWEEP");
+        p.debug_slot_sweep = (f && f[0] == '1') ? 1 : 0;
         const char *g = getenv("MVP_DEBUG_STAGE");
         p.debug_stage = g ? atoi(g) : 0;
     }
-    (void)bwd;
+#endif
     return MVP_OK;
 }
 
-extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir,
-                                 float stepsize, const float *tminmax, const float *nodeaabb, const float *primpos,
-                                 const float *primrot, const float *primscale, int TD, int TH, int TW,
-                                 const float *tplate, int WD, int WH, int WW, const float *warp, float *rayrgba,
-                                 float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
-                                 int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream) {
+struct CameraArgs {  // mvp_march_forward_cams: rays are made inside the march
+    const float *campos, *camrot, *focal, *princpt, *pixelcoords;
+    float volradius;
+};
+
+static int march_forward_impl(int N, int H, int W, int K, const float *raypos, const float *raydir, const CameraArgs *cams,
+                              float stepsize, const float *tminmax, const float *nodeaabb, const float *primpos,
+                              const float *primrot, const float *primscale, int TD, int TH, int TW,
+                              const float *tplate, int WD, int WH, int WW, const float *warp, float *rayrgba,
+                              float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
+                              int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream) {
     using namespace mvp;
     MarchParams p = {};
+    if (cams) {
+        p.campos = cams->campos, p.camrot = cams->camrot, p.focal = cams->focal, p.princpt = cams->princpt;
+        p.pixelcoords = cams->pixelcoords, p.volradius = cams->volradius;
+        if (!p.campos) return MVP_ERR_BADARG;
+    }
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
     p.WD = WD, p.WH = WH, p.WW = WW, p.warp = warp;
     if (warp && (WD < 2 || WH < 2 || WW < 2)) return MVP_ERR_UNSUPPORTED;
@@ -1833,6 +2182,30 @@ extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos
     return launch_status();
 }
 
+extern "C" int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir,
+                                 float stepsize, const float *tminmax, const float *nodeaabb, const float *primpos,
+                                 const float *primrot, const float *primscale, int TD, int TH, int TW,
+                                 const float *tplate, int WD, int WH, int WW, const float *warp, float *rayrgba,
+                                 float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
+                                 int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream) {
+    return march_forward_impl(N, H, W, K, raypos, raydir, nullptr, stepsize, tminmax, nodeaabb, primpos, primrot,
+                              primscale, TD, TH, TW, tplate, WD, WH, WW, warp, rayrgba, raysat, rayaux, primlist_count,
+                              primlist, primlist_cap, fadescale, fadeexp, diag, stream);
+}
+
+extern "C" int mvp_march_forward_cams(int N, int H, int W, int K, const float *campos, const float *camrot,
+                                      const float *focal, const float *princpt, const float *pixelcoords,
+                                      float volradius, float stepsize, const float *nodeaabb, const float *primpos,
+                                      const float *primrot, const float *primscale, int TD, int TH, int TW,
+                                      const float *tplate, float *rayrgba, float *raysat, uint32_t *rayaux,
+                                      uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale,
+                                      float fadeexp, uint32_t *diag, void *stream) {
+    const CameraArgs cams = {campos, camrot, focal, princpt, pixelcoords, volradius};
+    return march_forward_impl(N, H, W, K, nullptr, nullptr, &cams, stepsize, nullptr, nodeaabb, primpos, primrot,
+                              primscale, TD, TH, TW, tplate, 0, 0, 0, nullptr, rayrgba, raysat, rayaux, primlist_count,
+                              primlist, primlist_cap, fadescale, fadeexp, diag, stream);
+}
+
 extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir,
                                   float stepsize, const float *tminmax, const float *nodeaabb,
                                   const float *primpos, const float *primrot, const float *primscale, int TD,
@@ -1885,11 +2258,11 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     } else {
         const long long pb = 8ll * ((K + 7) / 8) * N;
         if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
-        // bound for the fixed-point scales: max |grad_rayrgba| into the tail of primlist_count (max |raysat| is there
-        // already, written by the forward)
-        hipLaunchKernelGGL(absmax_kernel, dim3(256 * 8), dim3(256), 0, st,
-                           reinterpret_cast<const float4 *>(grad_rayrgba), (size_t)N * H * W,
-                           p.pl_count + (size_t)N * K + 1);
+        // bounds for the fixed-point scales: per-packet max |grad_rayrgba| behind the tail of primlist_count (max |raysat|
+        // is in the tail already, written by the forward); also clears what an earlier backward left behind
+        hipLaunchKernelGGL(packetmax_kernel, dim3(256 * 8), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(grad_rayrgba), N, H, W, p.tiles_x, p.tiles_y,
+                           p.pl_count + (size_t)N * K + 3, p.pl_count, (size_t)N * K, p.pl_count + (size_t)N * K);
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         const dim3 grid((unsigned)pb), block(kPrimBlock);

@@ -34,6 +34,32 @@ __device__ __forceinline__ const T *at_bytes(const void *base, uint32_t byte_off
     return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
+// ---- pixel -> ray (utils_kernel.cu:12-52) -----------------------------------------------------------------------
+// One statement of the ray arithmetic for every kernel that makes rays (raydirs_kernel, and the march when it is handed
+// cameras instead of ray tensors): explicit fused operations under `fp contract(off)`, IEEE division and square root
+// (hipcc's default), so the same camera and pixel give the same bits wherever this is inlined.
+struct CamRay {
+    f3 o, d;
+    float tmin, tmax;
+};
+__device__ __forceinline__ CamRay ray_from_camera(f3 campos, const float *__restrict__ R /*[3,3] rows*/, float fx,
+                                                  float fy, float cx, float cy, float px, float py, float volradius) {
+#pragma clang fp contract(off)
+    CamRay c;
+    c.o = mk3(campos.x / volradius, campos.y / volradius, campos.z / volradius);  // utils_kernel.cu:32
+    const float qx = (px - cx) / fx, qy = (py - cy) / fy;
+    f3 d = mk3(__builtin_fmaf(R[3], qy, R[0] * qx) + R[6], __builtin_fmaf(R[4], qy, R[1] * qx) + R[7],
+               __builtin_fmaf(R[5], qy, R[2] * qx) + R[8]);
+    const float inv = 1.0f / sqrtf(__builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
+    d = mk3(d.x * inv, d.y * inv, d.z * inv);
+    c.d = d;
+    const f3 t1 = mk3((-1.f - c.o.x) / d.x, (-1.f - c.o.y) / d.y, (-1.f - c.o.z) / d.z);
+    const f3 t2 = mk3((1.f - c.o.x) / d.x, (1.f - c.o.y) / d.y, (1.f - c.o.z) / d.z);
+    c.tmin = fmaxf(max3f(fminf(t1.x, t2.x), fminf(t1.y, t2.y), fminf(t1.z, t2.z)), 0.f);
+    c.tmax = min3f(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y), fmaxf(t1.z, t2.z));
+    return c;
+}
+
 // ---- wave64 cross-lane helpers ------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }

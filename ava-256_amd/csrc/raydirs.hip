@@ -37,25 +37,17 @@ __global__ __launch_bounds__(kRdBlock) void raydirs_kernel(int N, int H, int W, 
                 hw = (int)(r - (long long)n * HW);
             }
             const int h = (int)((unsigned)hw / (unsigned)W), w = hw - h * W;
-            o = ld3(campos + n * 3);
-            o = mk3(o.x / volradius, o.y / volradius, o.z / volradius);
-            const float *R = camrot + n * 9;
             float px = (float)w, py = (float)h;
             if (pixelcoords) {
                 const float2 pc = reinterpret_cast<const float2 *>(pixelcoords)[r];
                 px = pc.x;
                 py = pc.y;
             }
-            const float qx = (px - princpt[n * 2 + 0]) / focal[n * 2 + 0];
-            const float qy = (py - princpt[n * 2 + 1]) / focal[n * 2 + 1];
-            d = mk3(R[0] * qx + R[3] * qy + R[6], R[1] * qx + R[4] * qy + R[7], R[2] * qx + R[5] * qy + R[8]);
-            const float inv = 1.0f / sqrtf(dot3(d, d));
-            d = d * inv;
-            const f3 t1 = mk3((-1.f - o.x) / d.x, (-1.f - o.y) / d.y, (-1.f - o.z) / d.z);
-            const f3 t2 = mk3((1.f - o.x) / d.x, (1.f - o.y) / d.y, (1.f - o.z) / d.z);
-            const float tmin = max3f(fminf(t1.x, t2.x), fminf(t1.y, t2.y), fminf(t1.z, t2.z));
-            const float tmax = min3f(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y), fmaxf(t1.z, t2.z));
-            reinterpret_cast<float2 *>(tminmax)[r] = make_float2(fmaxf(tmin, 0.f), tmax);
+            const CamRay c = ray_from_camera(ld3(campos + n * 3), camrot + n * 9, focal[n * 2 + 0], focal[n * 2 + 1],
+                                             princpt[n * 2 + 0], princpt[n * 2 + 1], px, py, volradius);
+            o = c.o;
+            d = c.d;
+            reinterpret_cast<float2 *>(tminmax)[r] = make_float2(c.tmin, c.tmax);
         }
         st3(s_pos + threadIdx.x * 3, o);
         st3(s_dir + threadIdx.x * 3, d);

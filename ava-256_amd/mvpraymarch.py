@@ -47,6 +47,153 @@ def build_accel(primtransfin, algo, fixedorder=False):
     return None, None, nodeaabb
 
 
+def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, template, warp, gradmode, options):
+    """Shared body of MVPRaymarch.forward (rays = (raypos, raydir, tminmax)) and MVPRaymarchFromCameras.forward
+    (cams = (campos, camrot, focal, princpt, pixelcoords-or-(W,H), volradius): the rays are made inside the march)."""
+    algo = options["algo"]
+    usebvh = options["usebvh"]
+    if algo not in (0, 1):
+        raise NotImplementedError("algo must be 0 (slab sampler) or 1 (warp-field sampler)")
+    if algo == 1 and warp is None:
+        raise RuntimeError("algo=1 needs a warp field")
+    if algo == 0:
+        warp = None  # PrimSamplerTW<false> never reads it (mvpraymarch_kernel.cu:89-95)
+    if usebvh != "fixedorder":
+        raise NotImplementedError("only usebvh='fixedorder' is implemented")
+    if options.get("randomorder", False):
+        raise NotImplementedError("randomorder is not implemented (the reference indexes dim 0 there, "
+                                  "mvpraymarch.py:139-140)")
+    if not options.get("chlast", True):
+        raise NotImplementedError("MVPRaymarch.forward takes channels-last templates; use mvpraymarch(chlast=False)")
+    fadescale, fadeexp = float(options["fadescale"]), float(options["fadeexp"])
+
+    primpos = require_device_f32("primpos", primpos)
+    primrot = require_device_f32("primrot", primrot)
+    primscale = require_device_f32("primscale", primscale)
+    template = require_device_f32("template", template)
+    if cams is None:
+        raypos, raydir, tminmax = rays
+        raypos = require_device_f32("raypos", raypos)
+        raydir = require_device_f32("raydir", raydir)
+        tminmax = require_device_f32("tminmax", tminmax)
+        assert raypos.dim() == 4 and raypos.size(3) == 3
+        assert raydir.shape == raypos.shape
+        assert tminmax.shape == raypos.shape[:3] + (2,)
+        N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
+        raypos, raydir, tminmax = aligned(raypos), aligned(raydir), aligned(tminmax)
+    else:
+        if warp is not None:
+            raise NotImplementedError("the fused camera entry point has no warp-field variant (algo 0 only)")
+        campos, camrot, focal, princpt, pixelcoords, volradius = cams
+        campos, camrot = require_device_f32("campos", campos), require_device_f32("camrot", camrot)
+        focal, princpt = require_device_f32("focal", focal), require_device_f32("princpt", princpt)
+        N = campos.size(0)
+        if isinstance(pixelcoords, tuple):
+            W, H = pixelcoords
+            pc = None
+        else:
+            pc = aligned(require_device_f32("pixelcoords", pixelcoords))
+            H, W = pc.size(1), pc.size(2)
+            assert pc.size(0) == N and pc.size(3) == 2
+        assert campos.shape == (N, 3) and camrot.shape == (N, 3, 3) and focal.shape == (N, 2) and princpt.shape == (N, 2)
+        raypos = raydir = tminmax = None
+    K = primpos.size(1)
+    assert primpos.shape == (N, K, 3) and primrot.shape == (N, K, 3, 3) and primscale.shape == (N, K, 3)
+    assert template.dim() == 6 and template.size(-1) == 4 and template.shape[:2] == (N, K)
+    TD, TH, TW = template.size(2), template.size(3), template.size(4)
+    dev = primpos.device
+    WD = WH = WW = 0
+    if warp is not None:
+        warp = aligned(require_device_f32("warp", warp))
+        assert warp.dim() == 6 and warp.size(-1) == 3 and warp.shape[:2] == (N, K)   # mvpraymarch.py:124
+        WD, WH, WW = warp.size(2), warp.size(3), warp.size(4)
+
+    template = aligned(template)
+    _, _, nodeaabb = build_accel((primpos, primrot, primscale), algo, fixedorder=True)
+
+    rayrgba = torch.empty((N, H, W, 4), device=dev, dtype=torch.float32)
+    raysat = rayaux = pl_count = pl_list = None
+    pl_cap = 0
+    if gradmode:
+        raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
+        if not _hooks.force_ray_centric_backward and warp is None:
+            # hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record
+            # and, per primitive, the list of ray packets that touch it
+            pl_cap = primlist_capacity(H, W, K)
+            rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
+            # counters + flags (zeroed by the library) + per-packet scratch of the backward (include/mvp_abi.h)
+            pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
+            pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
+        if cams is None:
+            _lib.check(_lib.get_lib().mvp_march_forward(
+                N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
+                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(rayrgba),
+                ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag),
+                stream_ptr(dev)), "mvp_march_forward")
+        else:
+            _lib.check(_lib.get_lib().mvp_march_forward_cams(
+                N, H, W, K, ptr(campos), ptr(camrot), ptr(focal), ptr(princpt), ptr(pc), float(volradius),
+                float(stepsize), ptr(nodeaabb), ptr(primpos), ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template),
+                ptr(rayrgba), ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp,
+                ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_forward_cams")
+
+    if _hooks.keep_raysat:
+        _hooks.last_raysat = raysat
+        _hooks.last_pl_count = pl_count
+    if cams is None:
+        ctx.cams = None
+        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
+                              pl_count, pl_list, warp)
+    else:  # the backward takes ray tensors: they are made there, only if a backward happens
+        ctx.cams = (pc is None, (W, H), float(volradius))
+        ctx.save_for_backward(campos, camrot, focal, princpt, pc, nodeaabb, primpos, primrot, primscale, template,
+                              raysat, rayaux, pl_count, pl_list)
+    ctx.pl_cap = pl_cap
+    ctx.options = options
+    ctx.stepsize = float(stepsize)
+    return rayrgba
+
+
+def _backward_impl(ctx, grad_rayrgba):
+    if ctx.cams is None:
+        (raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux, pl_count,
+         pl_list, warp) = ctx.saved_tensors
+    else:
+        (campos, camrot, focal, princpt, pc, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
+         pl_count, pl_list) = ctx.saved_tensors
+        warp = None
+        if raysat is not None:
+            from .raydirs import compute_raydirs
+            nopc, wh, volradius = ctx.cams
+            raypos, raydir, tminmax = compute_raydirs(campos, camrot, focal, princpt, wh if nopc else pc, volradius)
+    if raysat is None:
+        raise RuntimeError("backward through mvpraymarch needs grad mode enabled during the forward call")
+    fadescale, fadeexp = float(ctx.options["fadescale"]), float(ctx.options["fadeexp"])
+    N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
+    K = primpos.size(1)
+    TD, TH, TW = template.size(2), template.size(3), template.size(4)
+    dev = raypos.device
+    grad_rayrgba = aligned(grad_rayrgba.contiguous().float())
+
+    # the library overwrites every element of the four gradients: no zero-fill pass (the reference needs
+    # torch.zeros_like x4 here, mvpraymarch.py:240-246)
+    grad_primpos = torch.empty_like(primpos)
+    grad_primrot = torch.empty_like(primrot)
+    grad_primscale = torch.empty_like(primscale)
+    grad_template = torch.empty_like(template)
+    grad_warp = torch.empty_like(warp) if warp is not None else None
+    WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
+    with torch.cuda.device(dev), _hooks.timed("march_backward", dev):
+        _lib.check(_lib.get_lib().mvp_march_backward(
+            N, H, W, K, ptr(raypos), ptr(raydir), ctx.stepsize, ptr(tminmax), ptr(nodeaabb), ptr(primpos),
+            ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(raysat),
+            ptr(rayaux), ptr(pl_count), ptr(pl_list), ctx.pl_cap, ptr(grad_rayrgba), ptr(grad_primpos),
+            ptr(grad_primrot), ptr(grad_primscale), ptr(grad_template), ptr(grad_warp), fadescale, fadeexp,
+            ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_backward")
+    return grad_primpos, grad_primrot, grad_primscale, grad_template, grad_warp
+
+
 class MVPRaymarch(Function):
     """Custom Function for raymarching Mixture of Volumetric Primitives (same argument list as the reference's
     MVPRaymarch.forward, mvpraymarch.py:91-93)."""
@@ -54,107 +201,56 @@ class MVPRaymarch(Function):
     @staticmethod
     def forward(ctx, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, warp, rayterm,
                 gradmode, options):
-        algo = options["algo"]
-        usebvh = options["usebvh"]
-        if algo not in (0, 1):
-            raise NotImplementedError("algo must be 0 (slab sampler) or 1 (warp-field sampler)")
-        if algo == 1 and warp is None:
-            raise RuntimeError("algo=1 needs a warp field")
-        if algo == 0:
-            warp = None  # PrimSamplerTW<false> never reads it (mvpraymarch_kernel.cu:89-95)
-        if usebvh != "fixedorder":
-            raise NotImplementedError("only usebvh='fixedorder' is implemented")
-        if options.get("randomorder", False):
-            raise NotImplementedError("randomorder is not implemented (the reference indexes dim 0 there, "
-                                      "mvpraymarch.py:139-140)")
-        if not options.get("chlast", True):
-            raise NotImplementedError("MVPRaymarch.forward takes channels-last templates; use mvpraymarch(chlast=False)")
-        fadescale, fadeexp = float(options["fadescale"]), float(options["fadeexp"])
-
-        raypos = require_device_f32("raypos", raypos)
-        raydir = require_device_f32("raydir", raydir)
-        tminmax = require_device_f32("tminmax", tminmax)
-        primpos = require_device_f32("primpos", primpos)
-        primrot = require_device_f32("primrot", primrot)
-        primscale = require_device_f32("primscale", primscale)
-        template = require_device_f32("template", template)
-        assert raypos.dim() == 4 and raypos.size(3) == 3
-        assert raydir.shape == raypos.shape
-        assert tminmax.shape == raypos.shape[:3] + (2,)
-        N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
-        K = primpos.size(1)
-        assert primpos.shape == (N, K, 3) and primrot.shape == (N, K, 3, 3) and primscale.shape == (N, K, 3)
-        assert template.dim() == 6 and template.size(-1) == 4 and template.shape[:2] == (N, K)
-        TD, TH, TW = template.size(2), template.size(3), template.size(4)
-        dev = raypos.device
-        WD = WH = WW = 0
-        if warp is not None:
-            warp = aligned(require_device_f32("warp", warp))
-            assert warp.dim() == 6 and warp.size(-1) == 3 and warp.shape[:2] == (N, K)   # mvpraymarch.py:124
-            WD, WH, WW = warp.size(2), warp.size(3), warp.size(4)
-
-        raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
-        _, _, nodeaabb = build_accel((primpos, primrot, primscale), algo, fixedorder=True)
-
-        rayrgba = torch.empty((N, H, W, 4), device=dev, dtype=torch.float32)
-        raysat = rayaux = pl_count = pl_list = None
-        pl_cap = 0
-        if gradmode:
-            raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
-            if not _hooks.force_ray_centric_backward and warp is None:
-                # hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record
-                # and, per primitive, the list of ray packets that touch it
-                pl_cap = primlist_capacity(H, W, K)
-                rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
-                pl_count = torch.empty((N * K + 3,), device=dev, dtype=torch.int32)   # zeroed by the library
-                pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
-        with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
-            _lib.check(_lib.get_lib().mvp_march_forward(
-                N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
-                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(rayrgba),
-                ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag),
-                stream_ptr(dev)), "mvp_march_forward")
-
-        if _hooks.keep_raysat:
-            _hooks.last_raysat = raysat
-            _hooks.last_pl_count = pl_count
-        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
-                              pl_count, pl_list, warp)
-        ctx.pl_cap = pl_cap
-        ctx.options = options
-        ctx.stepsize = float(stepsize)
-        return rayrgba
+        return _forward_impl(ctx, (raypos, raydir, tminmax), None, stepsize, primpos, primrot, primscale, template,
+                             warp, gradmode, options)
 
     @staticmethod
     def backward(ctx, grad_rayrgba):
-        (raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux, pl_count,
-         pl_list, warp) = ctx.saved_tensors
-        if raysat is None:
-            raise RuntimeError("backward through mvpraymarch needs grad mode enabled during the forward call")
-        fadescale, fadeexp = float(ctx.options["fadescale"]), float(ctx.options["fadeexp"])
-        N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
-        K = primpos.size(1)
-        TD, TH, TW = template.size(2), template.size(3), template.size(4)
-        dev = raypos.device
-        grad_rayrgba = aligned(grad_rayrgba.contiguous().float())
+        gp, gr, gs, gt, gw = _backward_impl(ctx, grad_rayrgba)
+        return (None, None, None, None, gp, gr, gs, gt, gw, None, None, None)
 
-        # the library overwrites every element of the four gradients: no zero-fill pass (the reference needs
-        # torch.zeros_like x4 here, mvpraymarch.py:240-246)
-        grad_primpos = torch.empty_like(primpos)
-        grad_primrot = torch.empty_like(primrot)
-        grad_primscale = torch.empty_like(primscale)
-        grad_template = torch.empty_like(template)
-        grad_warp = torch.empty_like(warp) if warp is not None else None
-        WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
-        with torch.cuda.device(dev), _hooks.timed("march_backward", dev):
-            _lib.check(_lib.get_lib().mvp_march_backward(
-                N, H, W, K, ptr(raypos), ptr(raydir), ctx.stepsize, ptr(tminmax), ptr(nodeaabb), ptr(primpos),
-                ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(raysat),
-                ptr(rayaux), ptr(pl_count), ptr(pl_list), ctx.pl_cap, ptr(grad_rayrgba), ptr(grad_primpos),
-                ptr(grad_primrot), ptr(grad_primscale), ptr(grad_template), ptr(grad_warp), fadescale, fadeexp,
-                ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_backward")
-        return (None, None, None, None, grad_primpos, grad_primrot, grad_primscale, grad_template, grad_warp, None,
-                None, None)
+
+class MVPRaymarchFromCameras(Function):
+    """The same operator with the rays made inside the march kernel (mvp_march_forward_cams): the caller's
+    compute_raydirs + mvpraymarch pair (models/autoencoder.py:240-252) as one call, no ray tensors in HBM."""
+
+    @staticmethod
+    def forward(ctx, campos, camrot, focal, princpt, pixelcoords, volradius, stepsize, primpos, primrot, primscale,
+                template, gradmode, options):
+        return _forward_impl(ctx, None, (campos, camrot, focal, princpt, pixelcoords, volradius), stepsize, primpos,
+                             primrot, primscale, template, None, gradmode, options)
+
+    @staticmethod
+    def backward(ctx, grad_rayrgba):
+        gp, gr, gs, gt, _ = _backward_impl(ctx, grad_rayrgba)
+        return (None, None, None, None, None, None, None, gp, gr, gs, gt, None, None)
+
+
+_DEFAULT_OPTIONS = {"algo": 0, "usebvh": "fixedorder", "sortprims": False, "randomorder": False, "maxhitboxes": 512,
+                    "synchitboxes": True, "chlast": True, "fadescale": 8.0, "fadeexp": 8.0, "accum": 0,
+                    "termthresh": 0.0, "griddim": 3, "blocksize": (8, 16), "bwdblocksize": (8, 16)}
+
+
+def mvpraymarch_from_cameras(campos, camrot, focal, princpt, pixelcoords, volradius, stepsize, primtransf, template,
+                             **options):
+    """compute_raydirs(...) + mvpraymarch(...) in one call: same result bit for bit, without the
+    [N,H,W,3] + [N,H,W,3] + [N,H,W,2] ray tensors.  Options: the keyword arguments of mvpraymarch (algo 0 only).
+    pixelcoords: [N,H,W,2] tensor or a (W, H) tuple like compute_raydirs."""
+    unknown = set(options) - set(_DEFAULT_OPTIONS)
+    if unknown:
+        raise TypeError("unknown mvpraymarch option(s): %s" % sorted(unknown))
+    opts = dict(_DEFAULT_OPTIONS)
+    opts.update(options)
+    if not opts["chlast"]:
+        template = template.permute(0, 1, 3, 4, 5, 2).contiguous()
+        opts["chlast"] = True
+    if isinstance(primtransf, tuple):
+        primpos, primrot, primscale = primtransf
+    else:
+        primpos, primrot, primscale = (primtransf[:, :, 0, :].contiguous(), primtransf[:, :, 1:4, :].contiguous(),
+                                       primtransf[:, :, 4, :].contiguous())
+    return MVPRaymarchFromCameras.apply(campos, camrot, focal, princpt, pixelcoords, volradius, stepsize, primpos,
+                                        primrot, primscale, template, torch.is_grad_enabled(), opts)
 
 
 def mvpraymarch(

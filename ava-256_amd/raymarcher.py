@@ -14,7 +14,7 @@ from torch import nn
 
 from . import _lib
 from ._tensors import aligned, ptr, require_device_f32, stream_ptr
-from .mvpraymarch import mvpraymarch
+from .mvpraymarch import mvpraymarch, mvpraymarch_from_cameras
 
 # renderoptions are forwarded only when they name a keyword of mvpraymarch (the reference filters with
 # mvpraymarch.__code__.co_varnames, mvpraymarcher.py:45; the parameter list is the same set of names)
@@ -71,3 +71,17 @@ class Raymarcher(nn.Module):
                               warp=decout.get("warp", None), rayterm=rayterm, **opts)
         rayrgb, rayalpha, rayrgba_nchw = split_rgba_nchw(rayrgba)
         return rayrgb, rayalpha, rayrgba_nchw, None  # pos_img is always None in the reference as well
+
+    def forward_from_cameras(self, campos: torch.Tensor, camrot: torch.Tensor, focal: torch.Tensor,
+                             princpt: torch.Tensor, pixelcoords, decout: Dict[str, torch.Tensor],
+                             renderoptions: Optional[dict] = {}):
+        """The caller's two statements -- compute_raydirs(campos, camrot, focal, princpt, pixelcoords, volume_radius)
+        then forward(raypos, raydir, tminmax, decout) (models/autoencoder.py:240-252) -- as one kernel pass: the rays
+        are made inside the march (mvp_march_forward_cams), bit-identical to the two-call form, and never touch HBM.
+        Optional extension; the drop-in path is forward()."""
+        opts = {k: v for k, v in (renderoptions or {}).items() if k in _OPTION_NAMES}
+        prims = (decout["primpos"], decout["primrot"], decout["primscale"])
+        rayrgba = mvpraymarch_from_cameras(campos, camrot, focal, princpt, pixelcoords, self.volume_radius, self.dt,
+                                           prims, decout["template"], **opts)
+        rayrgb, rayalpha, rayrgba_nchw = split_rgba_nchw(rayrgba)
+        return rayrgb, rayalpha, rayrgba_nchw, None

@@ -11,8 +11,14 @@ the conv decoder would be:
                        template [B,K,8,8,8,4] = cat(relu(rgb*25+100), relu(alpha)), primpos, primrot, primscale) from
                        per-primitive parameters and a per-frame code; ~2k parameters per primitive, so K=16384 gives
                        a 134 MB gradient all-reduce -- the same order as ava-256's 187.5 MB.
-  RaymarchTrainModel   decoder -> compute_raydirs -> Raymarcher -> matting, like Autoencoder.decode
-                       (models/autoencoder.py:240-265).
+  ColorCalStandIn      per-camera + per-identity colour affine with the reference's parametrisation
+                       (models/colorcals/colorcal.py:11-31).
+  BackgroundMLPStandIn per-pixel background network with the reference's shape (models/bg/mlp2d.py:19-72: two small
+                       one-hot MLPs -> 40 + 40 channels, 40 positional-encoding channels, 1x1 convs 120 -> 256 x 5 -> 3,
+                       output * 25 + 100), run under torch.autocast(bfloat16) on the GPU: the one genuinely dense
+                       contraction next to the raymarch (154 GFLOP per 512^2 image), i.e. where MFMA belongs.
+  RaymarchTrainModel   decoder -> compute_raydirs -> Raymarcher -> colour calibration -> background -> matting
+                       `rayrgb + (1 - rayalpha) * bg`, the tail of Autoencoder.decode (models/autoencoder.py:240-269).
   Trainer              the loop body with the reference's semantics and hyper-parameters (configs/config.yaml:9-21).
 
 What is measured with it (bench.py --mode train) is therefore "iterations/s of the raymarch training path with a
@@ -67,17 +73,86 @@ class SlabDecoderStandIn(nn.Module):
         return {"template": template, "primpos": primpos, "primrot": primrot, "primscale": primscale}
 
 
+class ColorCalStandIn(nn.Module):
+    """w = wcam[cam] + wident[id], b = bcam[cam] + bident[id]; image * w + b per channel
+    (models/colorcals/colorcal.py:11-31: ones / zeros initialisation, so it starts as the identity)."""
+
+    def __init__(self, ncams: int, nident: int):
+        super().__init__()
+        self.wcam = nn.Parameter(torch.ones(ncams, 3))
+        self.bcam = nn.Parameter(torch.zeros(ncams, 3))
+        self.wident = nn.Parameter(torch.zeros(nident, 3))
+        self.bident = nn.Parameter(torch.zeros(nident, 3))
+
+    def forward(self, image, camindex, idindex):
+        w = self.wcam[camindex] + self.wident[idindex]
+        b = self.bcam[camindex] + self.bident[idindex]
+        return image * w[:, :, None, None] + b[:, :, None, None]
+
+
+class BackgroundMLPStandIn(nn.Module):
+    """Per-pixel background colour from (camera, identity, pixel position), the shape of models/bg/mlp2d.py:19-72:
+    one-hot camera / identity -> Linear(., 256) -> LeakyReLU(0.2) -> Linear(256, 40) each, 20 sin + 20 cos positional
+    channels of the normalised pixel coordinates, then 1x1 convolutions 120 -> 256 -> 256 -> 256 -> 256 -> 256 -> 3 with
+    LeakyReLU(0.2) between them, output * 25 + 100.  Per pixel that is 120*256 + 4*256^2 + 256*3 MACs = 0.59 MFLOP:
+    154 GFLOP per 512 x 512 image forward, the largest dense contraction of the training step.
+    `autocast_dtype` (bf16 by default) is applied on CUDA only: the 1x1 convolutions run as MFMA GEMMs."""
+
+    def __init__(self, ncams: int, nident: int, width: int = 256, autocast_dtype=torch.bfloat16, seed: int = 0):
+        super().__init__()
+        self.ncams, self.nident, self.autocast_dtype = ncams, nident, autocast_dtype
+        act = lambda: nn.LeakyReLU(0.2)
+        self.cammod = nn.Sequential(nn.Linear(ncams, 256), act(), nn.Linear(256, 40))
+        self.idmod = nn.Sequential(nn.Linear(nident, 256), act(), nn.Linear(256, 40))
+        # the reference's 1x1 Conv2d stack, held as Linear layers over a channels-last pixel matrix [b*h*w, C]: the same
+        # arithmetic, and each layer is one plain (pixels x C_in) @ (C_in x C_out) GEMM for hipBLASLt / MFMA
+        layers, cin = [], 120
+        for _ in range(5):
+            layers += [nn.Linear(cin, width), act()]
+            cin = width
+        layers += [nn.Linear(cin, 3)]
+        self.mlp = nn.Sequential(*layers)
+        g = torch.Generator().manual_seed(seed + 23)  # seeded: identical on every rank
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    fan_in = m.weight[0].numel()
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * math.sqrt(2.0 / fan_in))
+                    m.bias.zero_()
+
+    def forward(self, camindex, idindex, samplecoords):
+        b, h, w = samplecoords.shape[0], samplecoords.shape[1], samplecoords.shape[2]
+        dev = samplecoords.device
+        use_amp = dev.type == "cuda" and self.autocast_dtype is not None
+        with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype or torch.bfloat16, enabled=use_amp):
+            camenc = self.cammod(torch.nn.functional.one_hot(camindex, self.ncams).float())
+            idenc = self.idmod(torch.nn.functional.one_hot(idindex, self.nident).float())
+            freqs = (2.0 ** torch.arange(10, device=dev, dtype=torch.float32)) * math.pi
+            ang = samplecoords[..., None] * freqs                                   # [b,h,w,2,10]
+            posenc = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1).reshape(b, h, w, 40)
+            x = torch.cat([camenc[:, None, None, :].expand(b, h, w, 40).to(posenc.dtype),
+                           idenc[:, None, None, :].expand(b, h, w, 40).to(posenc.dtype), posenc], dim=-1)
+            out = self.mlp(x)                                                       # [b,h,w,3]
+        return out.float().permute(0, 3, 1, 2) * 25.0 + 100.0
+
+
 class RaymarchTrainModel(nn.Module):
-    """decoder -> rays -> raymarch -> matting (black background), the tail of Autoencoder.decode."""
+    """decoder -> rays -> raymarch -> colour calibration -> background -> matting: the tail of Autoencoder.decode
+    (models/autoencoder.py:225-269).  `colorcal` / `bgmodel` may be None (identity / black background, the reference's
+    own fallbacks at :255 and :263-267)."""
 
     def __init__(self, decoder: nn.Module, volradius: float = 256.0, dt: float = 1.0,
-                 renderer: Optional[Callable] = None):
+                 renderer: Optional[Callable] = None, colorcal: Optional[nn.Module] = None,
+                 bgmodel: Optional[nn.Module] = None):
         super().__init__()
         self.decoder = decoder
         self.raymarcher = Raymarcher(volradius, dt)
+        self.colorcal = colorcal
+        self.bgmodel = bgmodel
         self._renderer = renderer  # CPU tests inject a pure-torch stand-in; None = the gfx950 kernels
 
-    def forward(self, camrot, campos, focal, princpt, pixelcoords, code, schedule=None):
+    def forward(self, camrot, campos, focal, princpt, pixelcoords, code, schedule=None, camindex=None, idindex=None,
+                bg=None):
         self.last_schedule = schedule  # ddp-train.py:371-377; consumed by a real decoder's geometry branch
         decout = self.decoder(code)
         if self._renderer is not None:
@@ -86,7 +161,16 @@ class RaymarchTrainModel(nn.Module):
             raypos, raydir, tminmax = compute_raydirs(campos, camrot, focal, princpt, pixelcoords,
                                                       self.raymarcher.volume_radius)
             rayrgb, rayalpha, _, _ = self.raymarcher(raypos, raydir, tminmax, decout)
-        return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"]}
+        have_idx = camindex is not None and idindex is not None
+        if self.colorcal is not None and have_idx:                                   # autoencoder.py:254-256
+            rayrgb = self.colorcal(rayrgb, camindex, idindex)
+        if bg is None and self.bgmodel is not None and have_idx:                     # autoencoder.py:258-261
+            samplecoords = torch.cat([pixelcoords[..., :1] * 2 / (pixelcoords.shape[-2] - 1) - 1,
+                                      pixelcoords[..., 1:] * 2 / (pixelcoords.shape[-3] - 1) - 1], dim=-1)  # :231-237
+            bg = self.bgmodel(camindex, idindex, samplecoords)
+        if bg is not None:                                                           # autoencoder.py:263-265
+            rayrgb = rayrgb + (1.0 - rayalpha) * bg
+        return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"], "bg": bg}
 
 
 def forward_schedule(iternum: int) -> Dict[str, object]:
@@ -131,7 +215,8 @@ class Trainer:
 
     def step(self, batch: Dict[str, torch.Tensor]):
         output = self.model(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
-                            batch["code"], schedule=forward_schedule(self.iternum))
+                            batch["code"], schedule=forward_schedule(self.iternum), camindex=batch.get("camindex"),
+                            idindex=batch.get("idindex"))
         losses = self.losses(output, batch)
         loss = sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
         self.optim.zero_grad(set_to_none=False)
@@ -157,20 +242,25 @@ class Trainer:
 
 
 @torch.no_grad()
-def make_training_batch(N, H, W, K, device, seed=1112, code_dim=16, target_decoder: Optional[nn.Module] = None):
+def make_training_batch(N, H, W, K, device, seed=1112, code_dim=16, target_decoder: Optional[nn.Module] = None,
+                        ncams: int = 80, nident: int = 4, target_bg: float = 60.0):
     """Synthetic batch with the keys of the reference's data contract that this path uses:
-    cameras, pixel grid, a per-frame code and target images.  Targets are renders of a differently-seeded stand-in
-    decoder, so the optimisation has something real to fit."""
+    cameras, pixel grid, camindex / idindex, a per-frame code and target images.  Targets are renders of a
+    differently-seeded stand-in decoder matted over a flat grey background (`target_bg`, in the 0..255 image units of
+    the reference), so that the matting term carries gradient into rayalpha like a real captured frame does."""
     from .scene import make_cameras, pixel_grid
     cams = make_cameras(N, H, W, device=device, seed=seed)
     g = torch.Generator(device=device).manual_seed(seed + 5)
     batch = {k: cams[k] for k in ("camrot", "campos", "focal", "princpt")}
     batch["pixelcoords"] = pixel_grid(N, H, W, device=device)
     batch["code"] = torch.randn(N, code_dim, device=device, generator=g)
+    batch["camindex"] = torch.arange(N, device=device) % ncams
+    batch["idindex"] = (torch.arange(N, device=device) // ncams) % nident
     if target_decoder is not None:
         tm = RaymarchTrainModel(target_decoder.to(device))
+        bgt = torch.full((N, 3, H, W), float(target_bg), device=device)
         batch["image"] = tm(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
-                            batch["code"])["irgbrec"].clone()
+                            batch["code"], bg=bgt)["irgbrec"].clone()
     else:
         batch["image"] = torch.zeros(N, 3, H, W, device=device)
     return batch, cams["volradius"]

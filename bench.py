@@ -8,9 +8,20 @@ timed region.  Workload at N=1 (and per GPU for N>1, weak scaling): BASELINE.jso
 "C2": 1 subject, 80 cameras, 512x512, K=4096 primitives, 8^3 RGBA slabs, fp32.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
-(one rank per GPU, RCCL); rank 0 prints ONE JSON line.  Cameras are sharded across ranks with no data-path
-collective (render/march units are independent: SURVEY.md section 8e); the only collectives are the barriers
-and the MAX-reduce of the elapsed time.
+(one rank per GPU, RCCL); rank 0 prints ONE JSON line.  Every rank renders its own 80-camera scene (weak
+scaling; `--scaling strong` shards ONE scene's cameras over the ranks instead); there is no data-path
+collective (render/march units are independent: SURVEY.md section 8e) -- the only collectives of the march
+leg are the barriers and the MAX-reduce of the elapsed time.
+
+The same line carries a `train` object: iterations/s of the reference-shaped optimisation loop
+(ava-256_amd/trainloop.py: stand-in decoder -> rays -> march -> colour calibration -> bf16 background MLP ->
+matting -> L1 + primvolsum -> backward -> NaN mask -> clip -> Adam; DDP all-reduce of parameter gradients over
+RCCL when N>1), measured after the march leg on the same process group.
+
+The control flow (init, warm-up, barrier + synchronize, timed steps, MAX over ranks, rank-0 line) lives in
+`run_timed` / `main` and takes the process-group backend and the step factory as arguments, so that
+tests/test_bench_multirank.py can drive exactly this code with 2 gloo ranks on CPU (the kernels replaced by the
+CPU checker THERE, never here).
 """
 import argparse
 import json
@@ -51,11 +62,10 @@ def cpu_baseline(N, H, W, K, slab, budget_s=20.0):
 
     cores = os.cpu_count() or 1
     o = Oracle("f32")
-    n_img = 1
-    s = make_scene(n_img, H, W, K, device="cpu", seed=1112, slab=slab)
+    s = make_scene(1, H, W, K, device="cpu", seed=1112, slab=slab)
     npv = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in s.items()}
 
-    def one_pass(npv, n_img):
+    def one_pass():
         t0 = time.perf_counter()
         rp, rd, tm = o.raydirs(npv["campos"], npv["camrot"], npv["focal"], npv["princpt"], npv["pixelcoords"],
                                npv["volradius"])
@@ -64,109 +74,91 @@ def cpu_baseline(N, H, W, K, slab, budget_s=20.0):
         o.march_backward(*a, sat, np.ones_like(rgba))
         return time.perf_counter() - t0
 
-    t1 = one_pass(npv, 1)
+    t1 = one_pass()
     reps = int(max(1, min(16, budget_s / max(t1, 1e-3))))
     tt = t1
     for _ in range(reps - 1):
-        tt += one_pass(npv, 1)
+        tt += one_pass()
     rays = reps * H * W
     return {"value": rays / tt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d x (1 camera %dx%d, K=%d: raydirs+aabb+fwd+bwd) in %.1f s, OpenMP over rays, fp32" % (
                 reps, H, W, K, tt)}
 
 
-def train_mode(args, rank, local_rank, world, dev, dist):
-    """Reference-shaped training iterations (ava-256_amd/trainloop.py): stand-in decoder -> rays -> march fwd/bwd ->
-    L1 + primvolsum -> NaN mask -> clip -> Adam, DDP all-reduce of parameter gradients when world > 1."""
-    from ava256_amd import _hooks as mm
-    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer, make_training_batch
-    N, H, W, K, slab = WORKLOADS[args.workload]
-    batch, volradius = make_training_batch(N, H, W, K, dev, seed=1112 + rank,
-                                           target_decoder=SlabDecoderStandIn(K, slab, seed=9))
-    model = RaymarchTrainModel(SlabDecoderStandIn(K, slab, seed=1), volradius).to(dev)
-    nparams = sum(p.numel() for p in model.parameters())
-    tr = Trainer(model, ddp=world > 1, device_ids=[local_rank] if world > 1 else None)
+# ---------------------------------------------------------------------------------------------------------------
+# control flow shared by every leg (and by the 2-rank gloo test)
+# ---------------------------------------------------------------------------------------------------------------
+def env_ranks():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
 
+
+def init_process_group(backend, rank, world, dev):
+    """One process per GPU (backend "nccl" = RCCL) or per CPU rank (backend "gloo", tests).  None when world == 1."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist
+
+
+def run_timed(step, steps, warmup, dist, dev):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides;
+    returns the elapsed wall time, MAX over ranks."""
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step(batch)
+    for _ in range(warmup):
+        step()
     sync()
-    events = []
-    mm.set_event_sink(events)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = tr.step(batch)
+    for _ in range(steps):
+        step()
     sync()
     elapsed = time.perf_counter() - t0
-    mm.set_event_sink(None)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kt = {}
-    for name, a, b in events:
-        kt.setdefault(name, []).append(a.elapsed_time(b))
-    kavg = {k: sum(v) / len(v) for k, v in kt.items()}
-    if rank == 0:
-        print(json.dumps({
-            "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",
-            "value": args.steps / elapsed, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d frames/GPU, %dx%d, K=%d, %d^3 slabs" % (args.workload, N, H, W, K, slab),
-                       "parallelism": "DDP over %d rank(s), gradients only, one %0.1f MB bucket" % (world, nparams * 4e-6)},
-            "frames_per_s": N * world * args.steps / elapsed, "rays_per_s": N * H * W * world * args.steps / elapsed,
-            "allreduce_mb": nparams * 4e-6, "kernel_ms": kavg, "final_loss": float(loss)}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return elapsed
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--alpha-gain", type=float, default=1.0, help="1.0 = random-init opacity (nothing saturates)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="march", choices=["march", "train"],
-                    help="march (default, the contract metric): the raymarch hot path; train: the reference-shaped "
-                         "optimisation loop (stand-in decoder, DDP gradient all-reduce over RCCL) -> iterations/s")
-    args = ap.parse_args()
+def camera_shard(args, rank, world):
+    """Cameras this rank renders: its own N-camera scene (weak scaling, the default: per-GPU work fixed) or a
+    contiguous shard of ONE N-camera scene (strong scaling: total work fixed)."""
+    from ava256_amd.dist_util import shard_range
+    N = WORKLOADS[args.workload][0] if args.cams is None else args.cams
+    if args.scaling == "strong":
+        lo, hi = shard_range(N, rank, world)
+        return N, lo, hi, 1112          # same seed everywhere: one scene, sharded
+    return N, 0, N, 1112 + rank          # one scene per rank
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+# ---------------------------------------------------------------------------------------------------------------
+# the two GPU legs
+# ---------------------------------------------------------------------------------------------------------------
+def make_march_step_gpu(args, rank, world, dev):
+    """The hot path through the operator API on `dev`.  Returns (step, info)."""
     import ava256_amd as ops
-    from ava256_amd import _hooks as mm
     from ava256_amd.scene import make_scene
-
-    if args.mode == "train":
-        train_mode(args, rank, local_rank, world, dev, dist)
-        return
-
-    N, H, W, K, slab = WORKLOADS[args.workload]
-    s = make_scene(N, H, W, K, device=dev, seed=1112 + rank, alpha_gain=args.alpha_gain, slab=slab)
+    _, H, W, K, slab = WORKLOADS[args.workload]
+    N, lo, hi, seed = camera_shard(args, rank, world)
+    s = make_scene(N, H, W, K, device=dev, seed=seed, alpha_gain=args.alpha_gain, slab=slab)
     prim_names = ("primpos", "primrot", "primscale", "template")
+    cam_names = ("campos", "camrot", "focal", "princpt", "pixelcoords")
+    for k in prim_names + cam_names:
+        s[k] = s[k][lo:hi].contiguous()
     for k in prim_names:
         s[k].requires_grad_(True)
+    n_local = hi - lo
     torch.manual_seed(5 + rank)
-    gout = torch.randn(N, H, W, 4, device=dev)
+    gout = torch.randn(n_local, H, W, 4, device=dev)
     volradius, stepsize = s["volradius"], s["stepsize"]
 
     def step():
@@ -179,47 +171,130 @@ def main():
         rgba.backward(gout)
         return rgba
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N}
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    events = []
-    mm.set_event_sink(events)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    mm.set_event_sink(None)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # per-kernel average launch durations from the HIP events recorded inside the timed region
+def kernel_averages(events):
     kt = {}
     for name, a, b in events:
         kt.setdefault(name, []).append(a.elapsed_time(b))
-    kavg = {k: sum(v) / len(v) for k, v in kt.items()}
+    return {k: sum(v) / len(v) for k, v in kt.items()}
+
+
+def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg):
+    """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object."""
+    from ava256_amd import _hooks as mm
+    from ava256_amd.trainloop import (BackgroundMLPStandIn, ColorCalStandIn, RaymarchTrainModel, SlabDecoderStandIn,
+                                      Trainer, make_training_batch)
+    N, H, W, K, slab = WORKLOADS[workload]
+    ncams, nident = 80, 4
+    batch, volradius = make_training_batch(N, H, W, K, dev, seed=1112 + rank, ncams=ncams, nident=nident,
+                                           target_decoder=SlabDecoderStandIn(K, slab, seed=9))
+    model = RaymarchTrainModel(SlabDecoderStandIn(K, slab, seed=1), volradius, colorcal=ColorCalStandIn(ncams, nident),
+                               bgmodel=BackgroundMLPStandIn(ncams, nident) if with_bg else None).to(dev)
+    nparams = sum(p.numel() for p in model.parameters())
+    tr = Trainer(model, ddp=world > 1, device_ids=[local_rank] if world > 1 else None)
+    state = {}
+
+    def step():
+        state["loss"], _ = tr.step(batch)
+
+    events = []
+    for _ in range(warmup):
+        step()
+    mm.set_event_sink(events)
+    elapsed = run_timed(step, steps, 0, dist, dev)
+    mm.set_event_sink(None)
+    px = N * H * W
+    out = {"workload": "%s: %d frames/GPU, %dx%d, K=%d" % (workload, N, H, W, K), "iters_per_s": steps / elapsed,
+           "ms_per_iter": 1e3 * elapsed / steps, "steps": steps, "frames_per_s": N * world * steps / elapsed,
+           "allreduce_mb": nparams * 4e-6 if world > 1 else 0.0, "param_mb": nparams * 4e-6,
+           "kernel_ms": kernel_averages(events), "final_loss": float(state["loss"]),
+           "background_mlp": ("bf16 autocast, %.1f GFLOP fwd per iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
+           if with_bg else "off (black-free matting over a constant: 80 frames x 5 layers of 256-channel activations "
+                           "would hold ~54 GB for the backward)"}
+    del tr, model, batch
+    torch.cuda.empty_cache()
+    return out
+
+
+def main(argv=None, backend="nccl", make_step=None, device=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cams", type=int, default=None, help="override the camera count of the workload")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank renders its own scene; strong: ONE scene's cameras are sharded")
+    ap.add_argument("--alpha-gain", type=float, default=1.0, help="1.0 = random-init opacity (nothing saturates)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the train leg (profiling runs of the march kernels)")
+    ap.add_argument("--mode", default="march", choices=["march", "train"],
+                    help="march (default, the contract metric + a `train` object); train: only the training loop, as "
+                         "the headline value (iterations/s)")
+    args = ap.parse_args(argv)
+
+    rank, local_rank, world = env_ranks()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    gpu = device is None
+    if gpu:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device(device)  # tests only
+    dist = init_process_group(backend, rank, world, dev)
+
+    if args.mode == "train":
+        t = train_leg(args.workload, args.steps, args.warmup, rank, local_rank, world, dev, dist,
+                      with_bg=args.workload != "C2")
+        if rank == 0:
+            print(json.dumps({
+                "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",
+                "value": t["iters_per_s"], "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": t["ms_per_iter"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32 (march) + bf16 autocast (background MLP)", "data": "synthetic",
+                "config": {"workload": t["workload"], "parallelism": "DDP over %d rank(s), gradients only" % world},
+                "train": t}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    step, info = (make_step or make_march_step_gpu)(args, rank, world, dev)
+    events = []
+    if gpu:
+        from ava256_amd import _hooks as mm
+        for _ in range(args.warmup):
+            step()
+        mm.set_event_sink(events)
+        elapsed = run_timed(step, args.steps, 0, dist, dev)
+        mm.set_event_sink(None)
+    else:
+        elapsed = run_timed(step, args.steps, args.warmup, dist, dev)
+    kavg = kernel_averages(events)
+
+    # rays of all ranks per step: every rank contributes its own shard (gathered, so that uneven strong-scaling
+    # shards are counted exactly)
+    n_local = torch.tensor([info["n_local"]], device=dev, dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(n_local)
+    cams_total = int(n_local.item())
+    H, W, K, slab = info["H"], info["W"], info["K"], info["slab"]
+
+    train = None
+    if gpu and not args.no_train:
+        # the reference's other logged number (ddp-train.py:446,512): iterations/s of the loop, here on the raymarch
+        # training path with a stand-in decoder.  C3 = the reference's per-GPU batch shape (4 frames, K=16384) with the
+        # bf16 background MLP; C2 = the 80-frame render batch (background off, see train_leg).
+        train = {"note": "stand-in decoder (per-primitive slab parameters), NOT ava-256's conv stacks",
+                 "C3": train_leg("C3", 8, 2, rank, local_rank, world, dev, dist, with_bg=True),
+                 "C2": train_leg("C2", 4, 1, rank, local_rank, world, dev, dist, with_bg=False)}
 
     if rank == 0:
-        rays_per_step = N * H * W * world
-        bf, bb = algorithmic_bytes(N, H, W, K, slab ** 3)
-        dom = "march_backward" if kavg.get("march_backward", 0) >= kavg.get("march_forward", 0) else "march_forward"
-        dom_bytes = bb if dom == "march_backward" else bf
-        dom_ms = kavg.get(dom, float("nan"))
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 PMC passes
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
-            except Exception:
-                traffic = None
+        rays_per_step = cams_total * H * W
         out = {
             "metric": "rendered rays/sec, MVP raymarch training hot path (raydirs + AABB + march fwd + march bwd), "
                       "80-cam 512x512 K=4096 per GPU",
@@ -230,26 +305,43 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (seeded shell scene, random-init slab statistics; SURVEY.md 8d)",
             "config": {"workload": "%s: %d cams/GPU, %dx%d, K=%d primitives, %d^3 RGBA slabs, fadeexp=8, dt=1/256" % (
-                args.workload, N, H, W, K, slab), "alpha_gain": args.alpha_gain,
-                "parallelism": "cameras sharded over %d rank(s), no data-path collective" % world},
+                args.workload, info["N"] if args.scaling == "weak" else info["n_local"], H, W, K, slab),
+                "alpha_gain": args.alpha_gain,
+                "parallelism": ("every rank renders its own %d-camera scene" % info["N"] if args.scaling == "weak" else
+                                "%d cameras of one scene sharded" % cams_total) + " over %d rank(s), no data-path collective" % world},
             "iters_per_s": args.steps / elapsed,
-            "fwd_rays_per_s": (N * H * W) / (kavg["march_forward"] * 1e-3) if "march_forward" in kavg else None,
-            "kernel_ms": kavg,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "fwd": {"achieved": bf / (kavg.get("march_forward", float("nan")) * 1e-3) / 1e9,
-                                 "algorithmic_bytes_per_launch": bf,
-                                 "avg_launch_ms": kavg.get("march_forward")}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, H, W, K, slab)
-        print(json.dumps(out))
+        if kavg:
+            bf, bb = algorithmic_bytes(info["n_local"], H, W, K, slab ** 3)
+            dom = "march_backward" if kavg.get("march_backward", 0) >= kavg.get("march_forward", 0) else "march_forward"
+            dom_bytes = bb if dom == "march_backward" else bf
+            dom_ms = kavg.get(dom, float("nan"))
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 PMC passes
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                except Exception:
+                    traffic = None
+            out["fwd_rays_per_s"] = (info["n_local"] * H * W) / (kavg["march_forward"] * 1e-3) if "march_forward" in kavg else None
+            out["kernel_ms"] = kavg
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                               "fwd": {"achieved": bf / (kavg.get("march_forward", float("nan")) * 1e-3) / 1e9,
+                                       "algorithmic_bytes_per_launch": bf,
+                                       "avg_launch_ms": kavg.get("march_forward")}}
+        if train is not None:
+            out["train"] = train
+        if gpu and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(info["N"], H, W, K, slab)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

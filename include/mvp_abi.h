@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 6
+#define MVP_ABI_VERSION 8
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -50,7 +50,7 @@ extern "C" {
 #define MVP_DIAG_WORDS 8
 #define MVP_DIAG_FRONTIER_OVERFLOW 0 /* ray packets whose BFS frontier exceeded 512 -> exact DFS traversal      */
 #define MVP_DIAG_LIST_OVERFLOW 1     /* ray packets whose hit list exceeded 512 (reference cap, utils.h:779) */
-#define MVP_DIAG_SLOWPATH_PACKETS 2  /* packets that used primitives beyond the LDS-staged record window */
+#define MVP_DIAG_SLOWPATH_PACKETS 2  /* hit packets marched by the slot-synchronous sweep (over a fast-path limit) */
 #define MVP_DIAG_MAX_LIST 3          /* max hit-list length over all packets                             */
 #define MVP_DIAG_PACKETS_HIT 4       /* packets with a non-empty hit list                                */
 #define MVP_DIAG_LIST_ENTRIES 5      /* sum of hit-list lengths over all packets                         */
@@ -84,8 +84,11 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  * Grad-mode hand-off to the backward (all three may be NULL; then the backward uses its ray-centric path):
  *   rayaux          [N,H,W,4] uint32, fully written: {key of the saturating sample or 0xffffffff,
  *                   bits(alpha before it), first lattice step, bits(rtmax + 1e-5)}
- *   primlist_count  [N*K + 3] uint32, zeroed HERE (on `stream`) then filled: packets per primitive; then a flags
- *                   word and two words the backward uses (max |grad_rayrgba|, max |raysat|)
+ *   primlist_count  [N*K + 3 + N*ceil(H/8)*ceil(W/8)] uint32; the first N*K + 3 words are zeroed HERE (on `stream`) then
+ *                   filled: packets per primitive; a flags word; a reserved word; bits(max |raysat|).  The rest is
+ *                   scratch of the BACKWARD (per 8x8 ray packet: bits(max |grad_rayrgba|), rewritten by every call).
+ *                   The backward may be called several times over one forward (retain_graph): what it marks in
+ *                   this buffer (counter bit 31, flag bit 2) it clears again at the start of the next call.
  *   primlist        [N*K, primlist_cap, 2] uint32: per primitive the (packet, list slot, step range) records
  * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
 int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
@@ -94,6 +97,20 @@ int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const flo
                       const float *warp /*or NULL*/, float *rayrgba, float *raysat, uint32_t *rayaux,
                       uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale, float fadeexp,
                       uint32_t *diag, void *stream);
+
+/* Forward march with the rays made inside the kernel (first half; optional -- the drop-in path is
+ * the two calls above).  Fuses compute_raydirs_forward_cuda (utils_kernel.cu:12-52) into raymarch_forward_cuda for the
+ * caller models/autoencoder.py:240-252: no raypos / raydir / tminmax tensors are written or read (32 B per ray each
+ * way).  The rays are bit-identical to mvp_raydirs_forward's (one shared statement of the arithmetic), hence so is
+ * rayrgba.  pixelcoords may be NULL (integer pixel grid).  algo 0 only (no warp field).  The backward takes ray tensors:
+ * a caller that needs gradients makes them then (mvp_raydirs_forward) and calls mvp_march_backward. */
+int mvp_march_forward_cams(int N, int H, int W, int K, const float *campos /*[N,3]*/, const float *camrot /*[N,3,3]*/,
+                           const float *focal /*[N,2]*/, const float *princpt /*[N,2]*/,
+                           const float *pixelcoords /*[N,H,W,2] or NULL*/, float volradius, float stepsize,
+                           const float *nodeaabb, const float *primpos, const float *primrot, const float *primscale,
+                           int TD, int TH, int TW, const float *tplate, float *rayrgba, float *raysat, uint32_t *rayaux,
+                           uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale,
+                           float fadeexp, uint32_t *diag, void *stream);
 
 /* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
  * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are OVERWRITTEN (every element is written; the

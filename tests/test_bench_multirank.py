@@ -1,0 +1,91 @@
+"""bench.py's N>1 control flow on CPU: two gloo ranks run bench.main() itself -- process-group init, warm-up, barrier +
+MAX-reduce of the elapsed time, per-rank camera shards, rank-0 JSON line -- with the step factory replaced by one that
+renders with the CPU checker (in this test only; bench.py's own factory has no CPU path)."""
+import json
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_step_factory(args, rank, world, dev):
+    """Same contract as bench.make_march_step_gpu: (step, info); the shard comes from bench.camera_shard."""
+    import bench
+    from ava256_amd.scene import make_scene
+    from oracle.mvp_oracle import Oracle
+    H = W = 16
+    K = 32
+    N, lo, hi, seed = bench.camera_shard(args, rank, world)
+    s = make_scene(N, H, W, K, device="cpu", seed=seed, alpha_gain=5.0)
+    o = Oracle("f32")
+    sl = slice(lo, hi)
+    calls = {"n": 0}
+
+    def step():
+        rp, rd, tm = o.raydirs(s["campos"][sl].numpy(), s["camrot"][sl].numpy(), s["focal"][sl].numpy(),
+                               s["princpt"][sl].numpy(), s["pixelcoords"][sl].numpy(), s["volradius"])
+        o.march_forward(rp, rd, s["stepsize"], tm, s["primpos"][sl].numpy(), s["primrot"][sl].numpy(),
+                        s["primscale"][sl].numpy(), s["template"][sl].numpy())
+        calls["n"] += 1
+
+    step.calls = calls
+    return step, {"n_local": hi - lo, "H": H, "W": W, "K": K, "slab": 8, "N": N}
+
+
+def _worker(rank, world, port, outdir, scaling):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    import bench
+    from test_bench_multirank import _oracle_step_factory
+    out = open(os.path.join(outdir, "rank%d.out" % rank), "w")
+    sys.stdout = out
+    try:
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "C1", "--cams", "5",
+                    "--scaling", scaling], backend="gloo", make_step=_oracle_step_factory, device="cpu")
+    finally:
+        sys.stdout = sys.__stdout__
+        out.close()
+
+
+def _run(tmp_path, scaling):
+    port = _free_port()
+    d = tmp_path / scaling
+    d.mkdir()
+    mp.spawn(_worker, args=(2, port, str(d), scaling), nprocs=2, join=True)
+    r0 = open(d / "rank0.out").read().strip().splitlines()
+    assert open(d / "rank1.out").read().strip() == ""          # only rank 0 prints
+    assert len(r0) == 1                                        # ONE JSON line
+    return json.loads(r0[0])
+
+
+def test_bench_two_ranks_weak_scaling(tmp_path):
+    j = _run(tmp_path, "weak")
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["unit"] == "rays/s" and j["higher_is_better"] is True and j["vs_baseline"] is None
+    # whole-job aggregate: every rank renders its own 5 cameras -> 10 cameras of 16x16 rays per step
+    rays = 2 * 5 * 16 * 16
+    assert abs(j["value"] - rays * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) <= 1e-6 * j["value"]
+    assert "cpu_baseline" not in j and "train" not in j        # GPU-only legs
+
+
+def test_bench_two_ranks_strong_scaling(tmp_path):
+    from ava256_amd.dist_util import shard_range
+    j = _run(tmp_path, "strong")
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2
+    assert [shard_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]     # uneven shards are counted exactly:
+    rays = 5 * 16 * 16                                                     # 5 cameras in total, not 2 x ceil(5/2)
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - rays) <= 1e-6 * rays

@@ -1,0 +1,218 @@
+"""GPU tests of the corners the round-1 review named: the two forward sweeps must agree bit for bit, the fixed-point
+slab-gradient path under heavy-tailed upstream gradients and signed opacity, repeated backward passes over one forward,
+and the 512-entry hit-list cap (utils.h:779)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from helpers import FragileRays, cosine, npf, scene_rays, to_dev
+from test_gpu_parity import BACKWARD_MODES, FWD_TOL, _check_grads, _march, ops  # noqa: F401  (ops is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+DBG_LIB = os.path.join(ROOT, "build_variants", "libmvp_dbg.so")
+
+
+def _forward_with_handoff(ops_mod, d):
+    from ava256_amd import _hooks
+    _hooks.keep_raysat = True
+    rp, rd, tm = ops_mod.compute_raydirs(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"])
+    t = {k: d[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
+    rgba = ops_mod.mvpraymarch(rp, rd, d["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
+    sat, cnt = _hooks.last_raysat, _hooks.last_pl_count
+    _hooks.keep_raysat = False
+    _hooks.last_raysat = _hooks.last_pl_count = None
+    return rgba, sat, cnt, t
+
+
+@pytest.mark.skipif(not os.path.exists(DBG_LIB), reason="build_variants/libmvp_dbg.so not built (__graft_entry__.build())")
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 512, 1.0), (1, 200, 168, 4096, 20.0), (1, 96, 96, 16384, 6.0), (1, 40, 40, 300, 8.0)],
+                         ids=lambda c: "N%d_%dx%d_K%d_a%g" % c)
+def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
+    """The forward has two march schedules: the lane-independent sweep (every ray walks its own samples) and the
+    slot-synchronous one (the packet steps together; also the fallback beyond the fast path's limits).  Same sample
+    set, same order per ray, same arithmetic => rgba, raysat and the per-primitive packet counts must be IDENTICAL.
+    The debug build of the library (-DMVP_DEBUG_HOOKS) forces the slot-synchronous sweep through the environment."""
+    from ava256_amd import _hooks, _lib
+    from ava256_amd.scene import make_scene
+    N, H, W, K, again = cfg
+    s = make_scene(N, H, W, K, device="cuda", seed=5 + K, alpha_gain=again)
+    diag = torch.zeros(8, dtype=torch.int32, device="cuda")
+    _hooks.set_diag_buffer(diag)
+    rgba1, sat1, cnt1, _ = _forward_with_handoff(ops, s)
+    d1 = _hooks.read_diag()
+    assert d1["packets_hit"] > 0 and d1["slowpath_packets"] < d1["packets_hit"], d1   # the fast sweep really ran
+    diag.zero_()
+    os.environ["MVP_DEBUG_SLOT_SWEEP"] = "1"
+    _lib.use_library(DBG_LIB)
+    try:
+        rgba2, sat2, cnt2, _ = _forward_with_handoff(ops, s)
+        d2 = _hooks.read_diag()
+    finally:
+        del os.environ["MVP_DEBUG_SLOT_SWEEP"]
+        _lib.use_library(None)
+        _hooks.set_diag_buffer(None)
+    assert d2["slowpath_packets"] == d2["packets_hit"] == d1["packets_hit"], (d1, d2)
+    assert torch.equal(rgba1, rgba2)
+    assert torch.equal(sat1, sat2)
+    assert torch.equal(cnt1[: N * K], cnt2[: N * K])
+
+
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+def test_heavy_tailed_upstream_gradient(ops, oracle64, mode):
+    """0.1 % of the rays carry an upstream gradient 1e4 times the rest (a few bad pixels in an L1 image loss).  The
+    fixed-point scale of a primitive comes from the ray packets on ITS list, so primitives the outliers do not touch
+    keep full resolution: every primitive's slab gradient is held to 2e-4 of ITS OWN max |g| against float64."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 96, 96, 512
+    s = make_scene(N, H, W, K, device="cpu", seed=61, alpha_gain=2.0)
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    rng = np.random.default_rng(12)
+    gout = rng.normal(size=ref_rgba.shape)
+    outl = rng.random(size=ref_rgba.shape[:3]) < 1e-3
+    assert outl.sum() >= 5
+    gout[outl] *= 1.0e4
+    fragile = FragileRays(ref_sat, st["margin"], gout)
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, fragile.masked())
+    got = grads["template"].reshape(K, -1)
+    ref = rgt.reshape(K, -1)
+    pmax = np.abs(ref).max(1)
+    live = pmax > 0
+    rel = np.abs(got - ref).max(1)[live] / pmax[live]
+    print("heavy tail (%s): per-primitive relative error max %.2e median %.2e; max|g| spread %.1e" % (
+        mode, rel.max(), np.median(rel), pmax[live].max() / pmax[live].min()))
+    assert rel.max() <= 2e-4, rel.max()
+    assert not (~live).any() or np.abs(got[~live]).max() == 0.0
+    for k, refg in (("primpos", rgp), ("primrot", rgr), ("primscale", rgs)):
+        assert cosine(grads[k], refg) >= 0.9999, k
+
+
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+def test_signed_opacity(ops, oracle64, mode):
+    """The operator accepts any float template (the decoders relu theirs, the API does not): with negative opacity
+    the running alpha can go below zero, and the sample that finally saturates a ray gets weight 1 - alpha_before > 1,
+    outside the bound the fixed-point accumulators are scaled for.  Such primitives must be detected and come out of
+    the ray-centric kernel (fp32 atomics) -- gradients still match the oracle."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 64, 64, 256
+    s = make_scene(N, H, W, K, device="cpu", seed=33, alpha_gain=1.0)
+    g = torch.Generator().manual_seed(2)
+    tpl = s["template"].clone()
+    tpl[..., 3] = 120.0 * torch.randn(N, K, 1, 1, 1, generator=g).expand(N, K, 8, 8, 8) + 20.0 * torch.randn(N, K, 8, 8, 8, generator=g)
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), tpl.numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    assert ref_rgba[..., 3].min() < -0.2 and st["rays_saturated"] > 50       # alpha really goes negative, rays saturate
+    gout = np.random.default_rng(6).normal(size=ref_rgba.shape)
+    fragile = FragileRays(ref_sat, st["margin"], gout, max_frac=0.01, min_allowed=4)
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
+    fr = fragile.mask
+    err = np.abs(rgba - ref_rgba).max(-1)
+    assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0, err[~fr].max()
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, fragile.masked())
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "signed alpha " + mode)
+
+
+def test_backward_twice_over_one_forward(ops):
+    """retain_graph / several losses: the backward marks things in the forward's hand-off buffer (primitives it hands
+    to the ray-centric kernel) and derives its fixed-point scales from the upstream gradient of THAT call.  A second
+    backward must not inherit either: after a huge-gradient pass, and after a NaN pass, a small clean gradient gives
+    exactly what it gives on a fresh forward."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(2, 64, 64, 256, device="cuda", seed=9, alpha_gain=4.0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    small = 1e-3 * torch.randn(2, 64, 64, 4, device="cuda", generator=g)
+    huge = 1e6 * torch.randn(2, 64, 64, 4, device="cuda", generator=g)
+    poisoned = small.clone()
+    poisoned[0, 30, 30, 1] = float("nan")
+
+    rgba, _, cnt, t = _forward_with_handoff(ops, s)
+    rgba.backward(small)
+    fresh = {k: v.grad.clone() for k, v in t.items()}
+    assert all(torch.isfinite(v).all() for v in fresh.values())
+
+    for first in (huge, poisoned):
+        rgba, _, cnt, t = _forward_with_handoff(ops, s)
+        rgba.backward(first, retain_graph=True)
+        for v in t.values():
+            v.grad = None
+        rgba.backward(small)
+        flags = int(cnt[2 * 256].item())
+        assert flags == 0, flags                              # nothing stays handed over from the first pass
+        assert torch.equal(t["template"].grad, fresh["template"])
+        for k in ("primpos", "primrot", "primscale"):
+            assert torch.allclose(t[k].grad, fresh[k], rtol=1e-4, atol=1e-6 * float(fresh[k].abs().max())), k
+
+
+def test_hit_list_cap_matches_the_reference_rule(ops, oracle64):
+    """utils.h:779: a warp lists at most 512 primitives, in traversal (DFS leaf) order; later hits are dropped.  Here a
+    packet is an 8x8 wave instead of the reference's 8x4 warp; when every ray of the image hits every box, the kept
+    set is the same 512 for any packet shape, so the result must equal the oracle with maxhitboxes = 512 -- and the
+    drop is counted in diag, never silent."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 16, 16, 700
+    s = make_scene(N, H, W, K, device="cpu", seed=3, alpha_gain=1.0)
+    g = torch.Generator().manual_seed(4)
+    s["primpos"] = (0.01 * torch.randn(N, K, 3, generator=g)).contiguous()
+    s["primrot"] = torch.eye(3).expand(N, K, 3, 3).contiguous()
+    s["primscale"] = torch.full((N, K, 3), 1.0 / 0.8)
+    tpl = s["template"].clone()
+    tpl[..., 3] = 0.0002 * (1.0 + torch.rand(N, K, 8, 8, 8, generator=g))     # faint: no ray saturates
+    stepsize = 1.0 / 32.0
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, stepsize, tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), tpl.numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, maxhitboxes=512)
+    assert st["list_overflow"] == H * W * (K - 512) and st["rays_saturated"] == 0   # every ray hits every box
+    gout = np.random.default_rng(2).normal(size=ref_rgba.shape)
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=gout)
+    assert diag["list_overflow"] > 0 and diag["max_list"] == 512, diag
+    assert np.abs(rgba - ref_rgba).max() <= 4 * FWD_TOL * max(1.0, np.abs(ref_rgba).max())   # 512 x 50 samples per ray
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, gout, maxhitboxes=512)
+    kept = np.abs(rgt).reshape(K, -1).max(1) > 0
+    assert kept.sum() == 512
+    assert (np.abs(grads["template"]).reshape(K, -1).max(1) > 0).tolist() == kept.tolist()   # the same 512 are kept
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "list cap")
+
+
+@pytest.mark.parametrize("pixel_form", ["tensor", "tuple"])
+def test_fused_camera_entry_point_is_bit_identical(ops, pixel_form):
+    """SURVEY.md 8f row N1 (first half): mvp_march_forward_cams makes the rays inside the march.  One shared statement
+    of the ray arithmetic (mvp_device.h: ray_from_camera) => the image, raysat, and -- through a backward that makes the
+    ray tensors only then -- all gradients are IDENTICAL to compute_raydirs + mvpraymarch.  Ragged image, both forms
+    of pixelcoords (extensions/utils/utils.py:28-33)."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 3, 83, 101, 512
+    s = make_scene(N, H, W, K, device="cuda", seed=17, alpha_gain=8.0)
+    pc = s["pixelcoords"] if pixel_form == "tensor" else (W, H)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    gout = torch.randn(N, H, W, 4, device="cuda", generator=g)
+    names = ("primpos", "primrot", "primscale", "template")
+
+    t1 = {k: s[k].clone().requires_grad_(True) for k in names}
+    rp, rd, tm = ops.compute_raydirs(s["campos"], s["camrot"], s["focal"], s["princpt"], pc, s["volradius"])
+    a = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (t1["primpos"], t1["primrot"], t1["primscale"]), t1["template"], None)
+    a.backward(gout)
+
+    t2 = {k: s[k].clone().requires_grad_(True) for k in names}
+    b = ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], pc, s["volradius"], s["stepsize"],
+                                     (t2["primpos"], t2["primrot"], t2["primscale"]), t2["template"])
+    b.backward(gout)
+    assert torch.equal(a, b)
+    assert torch.equal(t1["template"].grad, t2["template"].grad)
+    for k in ("primpos", "primrot", "primscale"):
+        assert torch.equal(t1[k].grad, t2[k].grad), k
+    # the module-level form, no-grad
+    rm = ops.Raymarcher(s["volradius"], dt=1.0)
+    with torch.no_grad():
+        r1 = rm(rp, rd, tm, s)
+        r2 = rm.forward_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], pc, s)
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+    with pytest.raises(TypeError):
+        ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], pc, s["volradius"], s["stepsize"],
+                                     (s["primpos"], s["primrot"], s["primscale"]), s["template"], not_an_option=1)

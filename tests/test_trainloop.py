@@ -88,6 +88,39 @@ def test_nan_and_inf_gradients_are_zeroed():
     assert any(not torch.equal(q.detach(), q0) for q, q0 in [(model.decoder.rgb, torch.zeros_like(model.decoder.rgb))])
 
 
+def test_decode_tail_matches_the_reference_statements():
+    """Colour calibration, background and matting (models/autoencoder.py:254-265, models/colorcals/colorcal.py:27-31,
+    models/bg/mlp2d.py:58-72 for the network shape): irgbrec = (w * rayrgb + b) + (1 - rayalpha) * bg, and the gradient
+    that reaches rayalpha through the matting term is -bg * dL/dirgbrec summed over colour."""
+    from ava256_amd.trainloop import BackgroundMLPStandIn, ColorCalStandIn, RaymarchTrainModel, SlabDecoderStandIn
+    torch.manual_seed(1)
+    cc, bgm = ColorCalStandIn(5, 3), BackgroundMLPStandIn(5, 3)
+    with torch.no_grad():
+        cc.wcam.add_(0.1 * torch.randn_like(cc.wcam)), cc.bident.add_(torch.randn_like(cc.bident))
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer, colorcal=cc, bgmodel=bgm)
+    b = _batch(3, 6, 10, 0)
+    camindex, idindex = torch.tensor([0, 4, 2]), torch.tensor([1, 0, 2])
+    out = model(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], b["code"], camindex=camindex,
+                idindex=idindex)
+    decout = model.decoder(b["code"])
+    rgb, alpha = fake_renderer(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], decout)
+    w = (cc.wcam[camindex] + cc.wident[idindex])[:, :, None, None]
+    bb = (cc.bcam[camindex] + cc.bident[idindex])[:, :, None, None]
+    assert out["bg"].shape == (3, 3, 6, 10)
+    # the background network is a per-pixel function of (camera, identity, normalised pixel position): mlp2d.py:62-70
+    pc = b["pixelcoords"]
+    sc = torch.cat([pc[..., :1] * 2 / (pc.shape[-2] - 1) - 1, pc[..., 1:] * 2 / (pc.shape[-3] - 1) - 1], dim=-1)
+    assert float(sc.min()) == -1.0 and float(sc.max()) == 1.0
+    assert torch.allclose(out["bg"], bgm(camindex, idindex, sc))
+    assert torch.allclose(out["irgbrec"], (w * rgb + bb) + (1.0 - alpha) * out["bg"], rtol=1e-6, atol=1e-4)
+    # 120 -> 256 x 5 -> 3 per pixel, 40 + 40 + 40 input channels (mlp2d.py:29-41)
+    lin = [m for m in bgm.mlp if isinstance(m, torch.nn.Linear)]
+    assert [(m.in_features, m.out_features) for m in lin] == [(120, 256)] + [(256, 256)] * 4 + [(256, 3)]
+    # without indices the reference skips both stages and mattes over black (autoencoder.py:255,259,266-269)
+    out0 = model(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], b["code"])
+    assert out0["bg"] is None and torch.allclose(out0["irgbrec"], rgb)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
