@@ -1427,7 +1427,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // =================================================================================================
 #ifndef MVP_EXP
 // Timing experiments of the primitive-centric backward (tools/exp_variants.sh builds them, never the product library):
-//   1 = conflict-free scatter addresses, 2 = no scatter atomics (both compute WRONG gradients: time only),
+//   1 = conflict-free scatter addresses, 2 = no scatter atomics, 3 = no march at all (front-end chain: staging, phase 1,
+//   queue, phase-2 ray loads, output) -- all compute WRONG gradients: time only,
 //   4 = count same-address / same-bank lanes per 32-lane group into diag (tools/exp4_stats.py).
 #define MVP_EXP 0
 #endif
@@ -1792,7 +1793,12 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                 tend = __uint_as_float(aux.w);
             }
             const bool has_sat = rsat.x > -1.f;  // primaccum.h:93
+#if MVP_EXP == 3
+            // timing experiment: everything but the march itself (front-end chain only; the loaded values stay "used")
+            const int nsteps = (dL3.x + dLw + rsat.y + wbefore + tend + d.x + o.x + tmin == 12345.678f && satkey == 77u) ? 1 : 0;
+#else
             const int nsteps = uni(wave_max(len));
+#endif
             float ra0 = 0.f, ra1 = 0.f, ra2 = 0.f, rb0 = 0.f, rb1 = 0.f, rb2 = 0.f;
 #if MVP_EXP == 2
             int exp_sink = 0;

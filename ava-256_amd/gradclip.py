@@ -56,7 +56,7 @@ class GradClipper:
                        "mvp_grads_sanitize_sqnorm")
             _lib.check(lib.mvp_grads_clip_scale(n, ptrs, numels, self._sq.data_ptr(), float(max_norm),
                                                 self._norm.data_ptr(), stream), "mvp_grads_clip_scale")
-        return self._norm[0]
+        return self._norm[0].clone()  # a fresh scalar like clip_grad_norm_'s (the buffer is overwritten by the next call)
 
 
 def sanitize_and_clip_(params_or_grads, max_norm):

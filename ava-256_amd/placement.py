@@ -62,6 +62,18 @@ def _as_int32(idxim):
     return hit[1]
 
 
+def _check_indices(idxim, V):
+    """The kernels index geo with idxim directly; the reference's index_select raises on an index outside [0, V)
+    (assembler.py:118-122), so this does too -- once per index tensor version and V (one device reduction, cached)."""
+    key = (idxim._version, int(V))
+    if getattr(idxim, "_mvp_checked", None) == key:
+        return
+    lo, hi = int(idxim.min().item()), int(idxim.max().item())
+    if lo < 0 or hi >= V:
+        raise IndexError("idxim holds vertex indices in [%d, %d] but geo has %d vertices" % (lo, hi, V))
+    idxim._mvp_checked = key
+
+
 def prim_placement(geo, idxim, barim, volradius, nprims):
     """geo [B,V,3] float32 (de-normalised vertices), idxim [T,T,3] integer, barim [T,T,3] float32.
     Returns (primpos [B,nprims,3], vcenterdu [B,ny,nx,3], vcenterdv [B,ny,nx,3]) as assembler.py:143-206 computes them
@@ -77,4 +89,5 @@ def prim_placement(geo, idxim, barim, volradius, nprims):
         raise RuntimeError("idxim / barim must be [T, T, 3] with equal shapes")
     if not idxim.is_cuda or idxim.dtype not in (torch.int32, torch.int64):
         raise RuntimeError("idxim must be an int32/int64 tensor on the GPU")
+    _check_indices(idxim, geo.shape[1])
     return _Placement.apply(geo, _as_int32(idxim), barim, float(volradius), GRIDS[nprims])

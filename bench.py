@@ -37,6 +37,17 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# The reference's own code timed on CPU.  Its Python may not travel to the GPU box, so these are the measurements taken
+# where it is mounted (the build container: 8 cores, torch 2.10 CPU; BASELINE.md section 2, re-measurable with
+# tests/golden/gen_golden.py) -- carried beside the live `cpu_baseline` (this build's CPU port on the GPU box's cores).
+REFERENCE_CPU = {
+    "where": "build container, 8 CPU cores, torch 2.10.0 CPU (BASELINE.md section 2); NOT the GPU box's host",
+    "dense_raymarch_oracle": {"scene": "mvpraymarch.py gradcheck: N=2, 65x65, K=64, 32^3 slabs, fp32",
+                              "fwd_s": 9.12, "bwd_s": 13.02, "fwd_rays_per_s": 927.0, "fwd_bwd_rays_per_s": 382.0},
+    "autoencoder": {"model": "reference Autoencoder, K=16384, 46.9 M params, batch 1, 128x128, raymarch stubbed",
+                    "fwd_s": 4.6, "bwd_s": 1.5},
+}
+
 WORKLOADS = {
     # name: (N cams per GPU, H, W, K, slab)
     "C2": (80, 512, 512, 4096, 8),
@@ -341,6 +352,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             out["train"] = train
         if gpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(info["N"], H, W, K, slab)
+            out["reference_cpu"] = REFERENCE_CPU
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

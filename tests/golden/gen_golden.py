@@ -112,7 +112,9 @@ def save_march(name, **cfg):
 
 
 def save_raydirs(name, N=2, H=12, W=20, volradius=1.0):
-    """Dense ray generation exactly as extensions/utils/utils.py:130-148 states it (float64)."""
+    """Dense ray generation by the reference's own statement (extensions/utils/utils.py:126-148), executed in float64
+    from the mounted file on seeded inputs of this script's choosing (non-square focal, off-centre principal point,
+    half-pixel-offset coordinates: the reference's harness uses symmetric ones)."""
     torch.set_default_dtype(torch.float64)
     sys.modules["utilslib"] = types.ModuleType("utilslib")
     src = open(os.path.join(REF, "extensions/utils/utils.py")).read()
@@ -127,19 +129,18 @@ def save_raydirs(name, N=2, H=12, W=20, volradius=1.0):
     princpt = torch.tensor([[W * 0.5, H * 0.45] for n in range(N)])
     pixely, pixelx = torch.meshgrid(torch.arange(H).double(), torch.arange(W).double(), indexing="ij")
     pixelcoords = torch.stack([pixelx, pixely], dim=-1)[None].repeat(N, 1, 1, 1) + 0.25
-    # --- the reference's dense statement, utils.py:130-148 (volradius == 1 there) ---
-    raypos = viewpos[:, None, None, :].repeat(1, H, W, 1)
-    raydir = (pixelcoords - princpt[:, None, None, :]) / focal[:, None, None, :]
-    raydir = torch.cat([raydir, torch.ones_like(raydir[:, :, :, 0:1])], dim=-1)
-    raydir = torch.sum(viewrot[:, None, None, :, :] * raydir[:, :, :, :, None], dim=-2)
-    raydir = raydir / torch.sqrt(torch.sum(raydir ** 2, dim=-1, keepdim=True))
-    t1 = (-1.0 - viewpos[:, None, None, :]) / raydir
-    t2 = (1.0 - viewpos[:, None, None, :]) / raydir
-    tmin = torch.max(torch.min(t1[..., 0], t2[..., 0]),
-                     torch.max(torch.min(t1[..., 1], t2[..., 1]), torch.min(t1[..., 2], t2[..., 2]))).clamp(min=0.0)
-    tmax = torch.min(torch.max(t1[..., 0], t2[..., 0]),
-                     torch.min(torch.max(t1[..., 1], t2[..., 1]), torch.max(t1[..., 2], t2[..., 2])))
-    tminmax = torch.stack([tmin, tmax], dim=-1)
+    # --- the reference's dense statement, utils.py:126-148 (volradius == 1 there), EXECUTED from the mounted file:
+    #     the lines between its "run pytorch version" banner and `sample0 = raydir` are read at run time and exec'd on
+    #     these inputs; nothing of the reference's source is stored in this repository ---
+    lines = src.splitlines()
+    first = next(i for i, ln in enumerate(lines) if "run pytorch version" in ln) + 1
+    last = next(i for i, ln in enumerate(lines) if i > first and ln.strip() == "sample0 = raydir")
+    import textwrap
+    stmt = textwrap.dedent("\n".join(lines[first:last]))
+    env = dict(torch=torch, H=H, W=W, _viewpos=viewpos, _viewrot=viewrot, _focal=focal, _princpt=princpt,
+               _pixelcoords=pixelcoords)
+    exec(compile(stmt, "refutils_dense_rays", "exec"), env)
+    raypos, raydir, tminmax = env["raypos"], env["raydir"], env["tminmax"]
     torch.set_default_dtype(torch.float32)
     out = dict(viewpos=viewpos, viewrot=viewrot, focal=focal, princpt=princpt, pixelcoords=pixelcoords,
                volradius=np.float64(volradius), raypos=raypos, raydir=raydir, tminmax=tminmax)

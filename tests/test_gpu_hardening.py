@@ -184,7 +184,8 @@ def test_hit_list_cap_matches_the_reference_rule(ops, oracle64):
 def test_fused_camera_entry_point_is_bit_identical(ops, pixel_form):
     """SURVEY.md 8f row N1 (first half): mvp_march_forward_cams makes the rays inside the march.  One shared statement
     of the ray arithmetic (mvp_device.h: ray_from_camera) => the image, raysat, and -- through a backward that makes the
-    ray tensors only then -- all gradients are IDENTICAL to compute_raydirs + mvpraymarch.  Ragged image, both forms
+    ray tensors only then -- the slab gradient are IDENTICAL to compute_raydirs + mvpraymarch (pose gradients to fp32
+    round-off: their ray sums are not order-deterministic in either form).  Ragged image, both forms
     of pixelcoords (extensions/utils/utils.py:28-33)."""
     from ava256_amd.scene import make_scene
     N, H, W, K = 3, 83, 101, 512
@@ -205,8 +206,8 @@ def test_fused_camera_entry_point_is_bit_identical(ops, pixel_form):
     b.backward(gout)
     assert torch.equal(a, b)
     assert torch.equal(t1["template"].grad, t2["template"].grad)
-    for k in ("primpos", "primrot", "primscale"):
-        assert torch.equal(t1[k].grad, t2[k].grad), k
+    for k in ("primpos", "primrot", "primscale"):  # fp32 sums over rays in queue order (LDS tickets): equal to round-off
+        assert (t1[k].grad - t2[k].grad).abs().max().item() <= 1e-4 * t1[k].grad.abs().max().item(), k
     # the module-level form, no-grad
     rm = ops.Raymarcher(s["volradius"], dt=1.0)
     with torch.no_grad():

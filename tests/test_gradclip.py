@@ -124,3 +124,8 @@ def test_hip_rejects_wrong_inputs():
     with pytest.raises(RuntimeError):
         c([torch.zeros(4, 4, device=dev).t()[1:]], 1.0)
     assert float(c([], 1.0)) == 0.0
+    # the returned norm is a fresh scalar (like clip_grad_norm_'s): a later call must not change an earlier result
+    g1, g2 = torch.full((10,), 3.0, device=dev), torch.full((10,), 0.5, device=dev)
+    n1 = c([g1], 100.0)
+    n2 = c([g2], 100.0)
+    assert abs(float(n1) - 3.0 * 10 ** 0.5) < 1e-5 and abs(float(n2) - 0.5 * 10 ** 0.5) < 1e-6

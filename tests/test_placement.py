@@ -73,3 +73,10 @@ def test_hip_placement_errors():
         prim_placement(g, idx[:512], bar[:512], volradius, 256)  # not square
     with pytest.raises(RuntimeError):
         prim_placement(g, idx[:512, :512].contiguous(), bar[:512, :512].contiguous(), volradius, 256)  # grid beyond the map
+    bad = idx.clone()
+    bad[100, 200, 1] = g.shape[1]                          # one past the last vertex: index_select would raise
+    with pytest.raises(IndexError):
+        prim_placement(g, bad, bar, volradius, 256)
+    bad[100, 200, 1] = -1
+    with pytest.raises(IndexError):
+        prim_placement(g, bad, bar, volradius, 256)
