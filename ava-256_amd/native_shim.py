@@ -1,0 +1,136 @@
+"""Native-module shims: the reference's two pybind modules, re-created over the C ABI with their POSITIONAL signatures.
+
+The drop-in boundary of this build is the operator layer (`mvpraymarch`, `compute_raydirs`, `Raymarcher`).
+This file adds the layer below it: functions with exactly the parameter lists of `mvpraymarchlib`
+(extensions/mvpraymarch/mvpraymarch.cpp:146-396 -> `compute_morton, build_tree, compute_aabb, raymarch_forward,
+raymarch_backward`, registered at :398-405) and `utilslib` (extensions/utils/utils.cpp:46-82 ->
+`compute_raydirs_forward, compute_raydirs_backward`, :134-137), so that the reference's UNMODIFIED
+`extensions/mvpraymarch/mvpraymarch.py` and `extensions/utils/utils.py` can keep their `from . import mvpraymarchlib` /
+`from . import utilslib`: copy `extensions/mvpraymarch/mvpraymarchlib.py` and `extensions/utils/utilslib.py` of this
+repository (two-line re-exports of this module) next to them instead of building the CUDA extensions.
+
+What the shims do with arguments the gfx950 kernels have no use for:
+  sortedobjid, nodechildren, nodeparent   ignored: the fixed-order tree is implicit (only usebvh="fixedorder" is valid;
+                                          compute_morton / build_tree raise -- the reference's traversal never reads the
+                                          LBVH topology they would build, utils.h:742,788)
+  sortprims, maxhitboxes, synchitboxes, accum, termthresh, griddim, blocksizex/y, rayterm
+                                          ignored like the reference's kernels ignore them (hard-wired template
+                                          arguments, mvpraymarch_kernel.cu:33,101-102,188-189)
+  chlast = False                          rejected (the reference's sampler is instantiated channels-last only)
+The forward keeps the hand-off buffers of the primitive-centric backward (rayaux, packet lists) in a small cache keyed
+by the `rayrgba` tensor the reference's autograd Function saves and passes back, so the backward runs the fast path.
+"""
+import collections
+
+import torch
+
+from . import _hooks, _lib
+from ._tensors import aligned, ptr, require_device_f32, stream_ptr
+from .mvpraymarch import primlist_capacity
+
+_HANDOFF = collections.OrderedDict()  # rayrgba.data_ptr() -> (rayaux, pl_count, pl_list, pl_cap)
+_HANDOFF_MAX = 8
+
+
+def compute_morton(*args):
+    raise NotImplementedError("compute_morton: only usebvh='fixedorder' is supported (the reference's traversal "
+                              "ignores the LBVH topology, utils.h:742,788)")
+
+
+def build_tree(*args):
+    raise NotImplementedError("build_tree: only usebvh='fixedorder' is supported")
+
+
+def compute_aabb(primpos, primrot, primscale, sortedobjid, nodechildren, nodeparent, nodeaabb, algo):
+    """mvpraymarch.cpp:198-230 -> mvp_aabb_build."""
+    primpos, primrot, primscale = (require_device_f32(n, t) for n, t in
+                                   (("primpos", primpos), ("primrot", primrot), ("primscale", primscale)))
+    N, K = primpos.size(0), primpos.size(1)
+    assert nodeaabb.is_contiguous() and tuple(nodeaabb.shape) == (N, 2 * K - 1, 2, 3) and nodeaabb.dtype == torch.float32
+    dev = primpos.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.get_lib().mvp_aabb_build(N, K, ptr(primpos), ptr(primrot), ptr(primscale), ptr(nodeaabb),
+                                                stream_ptr(dev)), "mvp_aabb_build")
+
+
+def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildren, nodeaabb, primpos, primrot,
+                     primscale, template, warp, rayrgba, raysat, rayterm, algo=0, sortprims=True, maxhitboxes=512,
+                     synchitboxes=False, chlast=False, fadescale=8.0, fadeexp=8.0, accum=0, termthresh=0.0, griddim=3,
+                     blocksizex=8, blocksizey=16):
+    """mvpraymarch.cpp:180-280 (same defaults) -> mvp_march_forward.  `raysat` given = grad mode (mvpraymarch.py:147-152)."""
+    if not chlast:
+        raise NotImplementedError("channels-first templates: the reference instantiates only the channels-last sampler")
+    if algo not in (0, 1):
+        raise NotImplementedError("algo must be 0 or 1")
+    for n, t in (("raypos", raypos), ("raydir", raydir), ("tminmax", tminmax), ("nodeaabb", nodeaabb),
+                 ("primpos", primpos), ("primrot", primrot), ("primscale", primscale), ("template", template)):
+        require_device_f32(n, t)
+    N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
+    K = primpos.size(1)
+    TD, TH, TW = template.size(2), template.size(3), template.size(4)
+    dev = raypos.device
+    if algo == 0:
+        warp = None
+    WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
+    raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
+    rayaux = pl_count = pl_list = None
+    pl_cap = 0
+    if raysat is not None and warp is None:
+        pl_cap = primlist_capacity(H, W, K)
+        rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
+        pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
+        pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
+        _HANDOFF[rayrgba.data_ptr()] = (rayaux, pl_count, pl_list, pl_cap)
+        while len(_HANDOFF) > _HANDOFF_MAX:
+            _HANDOFF.popitem(last=False)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.get_lib().mvp_march_forward(
+            N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
+            ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(rayrgba), ptr(raysat),
+            ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, float(fadescale), float(fadeexp), ptr(_hooks.diag),
+            stream_ptr(dev)), "mvp_march_forward")
+
+
+def raymarch_backward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildren, nodeaabb, primpos, grad_primpos,
+                      primrot, grad_primrot, primscale, grad_primscale, template, grad_template, warp, grad_warp,
+                      rayrgba, grad_rayrgba, raysat, rayterm, algo=0, sortprims=True, maxhitboxes=512, synchitboxes=False,
+                      chlast=False, fadescale=8.0, fadeexp=8.0, accum=0, termthresh=0.0, griddim=3, blocksizex=8,
+                      blocksizey=16):
+    """mvpraymarch.cpp:282-396 (same defaults) -> mvp_march_backward (the gradient buffers are overwritten; the zeros the reference
+    pre-fills them with, mvpraymarch.py:240-246, are not needed)."""
+    if not chlast:
+        raise NotImplementedError("channels-first templates: the reference instantiates only the channels-last sampler")
+    N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
+    K = primpos.size(1)
+    TD, TH, TW = template.size(2), template.size(3), template.size(4)
+    dev = raypos.device
+    if algo == 0:
+        warp = grad_warp = None
+    WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
+    rayaux, pl_count, pl_list, pl_cap = _HANDOFF.pop(rayrgba.data_ptr(), (None, None, None, 0))
+    grad_rayrgba = aligned(require_device_f32("grad_rayrgba", grad_rayrgba))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.get_lib().mvp_march_backward(
+            N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
+            ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(raysat), ptr(rayaux),
+            ptr(pl_count), ptr(pl_list), pl_cap, ptr(grad_rayrgba), ptr(grad_primpos), ptr(grad_primrot),
+            ptr(grad_primscale), ptr(grad_template), ptr(grad_warp), float(fadescale), float(fadeexp), ptr(_hooks.diag),
+            stream_ptr(dev)), "mvp_march_backward")
+
+
+def compute_raydirs_forward(viewpos, viewrot, focal, princpt, pixelcoords, W, H, volradius, raypos, raydir, tminmax):
+    """utils.cpp:46-64 -> mvp_raydirs_forward (pixelcoords may be None: integer pixel grid)."""
+    for n, t in (("viewpos", viewpos), ("viewrot", viewrot), ("focal", focal), ("princpt", princpt)):
+        require_device_f32(n, t)
+    N = viewpos.size(0)
+    dev = viewpos.device
+    pc = aligned(require_device_f32("pixelcoords", pixelcoords)) if pixelcoords is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.get_lib().mvp_raydirs_forward(N, int(H), int(W), ptr(viewpos), ptr(viewrot), ptr(focal),
+                                                     ptr(princpt), ptr(pc), float(volradius), ptr(raypos), ptr(raydir),
+                                                     ptr(tminmax), stream_ptr(dev)), "mvp_raydirs_forward")
+
+
+def compute_raydirs_backward(*args):
+    """utils.cpp:66-82: the reference's backward kernel writes nothing (utils_kernel.cu:54-95); neither does this."""
+    return None

@@ -90,6 +90,42 @@ class ColorCalStandIn(nn.Module):
         return image * w[:, :, None, None] + b[:, :, None, None]
 
 
+class _PixelLinearFn(torch.autograd.Function):
+    """y = x @ W^T + b for a tall pixel matrix x [M, C_in] (M ~ 10^6, C <= 256).  Forward and input gradient are the GEMMs
+    torch would issue anyway; the WEIGHT gradient x^T @ dy has a 256 x 256 output and K = M, for which hipBLASLt picks a
+    64x64 tile without split-K (16 workgroups on 256 CUs: 1.9 ms = 72 TFLOP/s at M = 2^20, `profiles/r02h_*`).  Here
+    it is a batched GEMM over `chunks` row blocks (1024 workgroups) whose partial products are summed in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chunks):
+        ctx.save_for_backward(x, weight)
+        ctx.chunks = chunks
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        M = x.shape[0]
+        S = ctx.chunks if M % ctx.chunks == 0 else 1
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(gy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).float().sum(0).to(weight.dtype)
+        gb = gy.float().sum(0).to(gy.dtype)
+        return gx, gw, gb, None
+
+
+class PixelLinear(nn.Linear):
+    """nn.Linear over a [..., C_in] pixel tensor; on CUDA under autocast the weight gradient is the chunked form above."""
+
+    def forward(self, x):
+        if x.is_cuda and torch.is_autocast_enabled() and x.shape[:-1].numel() >= 1 << 16:
+            dt = torch.get_autocast_dtype("cuda")
+            lead = x.shape[:-1]
+            y = _PixelLinearFn.apply(x.reshape(-1, x.shape[-1]).to(dt), self.weight.to(dt), self.bias.to(dt), 64)
+            return y.view(*lead, -1)
+        return super().forward(x)
+
+
 class BackgroundMLPStandIn(nn.Module):
     """Per-pixel background colour from (camera, identity, pixel position), the shape of models/bg/mlp2d.py:19-72:
     one-hot camera / identity -> Linear(., 256) -> LeakyReLU(0.2) -> Linear(256, 40) each, 20 sin + 20 cos positional
@@ -108,9 +144,9 @@ class BackgroundMLPStandIn(nn.Module):
         # arithmetic, and each layer is one plain (pixels x C_in) @ (C_in x C_out) GEMM for hipBLASLt / MFMA
         layers, cin = [], 120
         for _ in range(5):
-            layers += [nn.Linear(cin, width), act()]
+            layers += [PixelLinear(cin, width), act()]
             cin = width
-        layers += [nn.Linear(cin, 3)]
+        layers += [PixelLinear(cin, 3)]
         self.mlp = nn.Sequential(*layers)
         g = torch.Generator().manual_seed(seed + 23)  # seeded: identical on every rank
         with torch.no_grad():
