@@ -47,13 +47,19 @@ constexpr int kStartDepth = 10;   // the BFS tests every node of this depth firs
 constexpr int kNoSlot = 255;
 // Lane-independent forward sweep (see march_packet): per-ray crossing table in LDS, kFastCross rows of 64 lanes.
 // Row index 31 is the null link, so a ray can hold at most min(kFastCross, 31) crossings; packets beyond any of the
-// limits below are marched by the slot-synchronous sweep instead (same results, slower).
+// limits below are marched by the slot-synchronous sweep instead (same results, slower).  kFastSlots records (64 B each)
+// + kFastCross rows (256 B each) share the 8 KB the slot-synchronous layout needs: 40 + 22 keeps 5 waves per SIMD and
+// measured best over C2/C3/C4 (64 + 24 at 10 KB, 48 + 20, 56 + 18 and 64 + 16 at 8 KB were within 3 %).
 #ifndef MVP_FAST_CROSS
-#define MVP_FAST_CROSS 24
+#define MVP_FAST_CROSS 22
 #endif
 constexpr int kFastCross = MVP_FAST_CROSS;
 constexpr int kFastMaxCross = kFastCross < 31 ? kFastCross : 31;
-constexpr int kFastSlots = 64;    // list slots (6-bit field; also: every record is LDS-resident)
+#ifndef MVP_FAST_RECS
+#define MVP_FAST_RECS 40
+#endif
+constexpr int kFastSlots = MVP_FAST_RECS;  // list slots (6-bit field; every record of the fast path is LDS-resident) =
+                                           // records staged in fast mode; the crossing table starts right behind them
 constexpr int kFastCand = 128;    // BVH candidates (two registers per lane)
 constexpr int kFastMaxLen = 64;   // lattice steps of one crossing (6-bit field)
 constexpr int kFastMaxStep = 32767;  // largest lattice-step index (15-bit field)
@@ -678,8 +684,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 }
                 kk0 = kk[0];
             }
-            // stage the SRT records of the first 64 candidates: lanes over candidates, one gather round trip
-            if (lane < ncand && lane < kRecSlots) rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk0), kk0);
+            // stage the SRT records of the first 64 candidates (fast mode: kFastSlots, the table follows them): lanes
+            // over candidates, one gather round trip
+            if (lane < ncand && lane < (fast ? kFastSlots : kRecSlots))
+                rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk0), kk0);
             __syncthreads();
         }
     }
@@ -704,7 +712,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         bool wfail = false;
         for (int c = 0; c < ncand; ++c) {
             const int k = c < kWave ? __builtin_amdgcn_readlane(kk0, c) : __builtin_amdgcn_readlane(kk1, c - kWave);
-            const bool inlds = c < kRecSlots;
+            const bool inlds = c < kFastSlots;
             Rec qg;
             if (!inlds) qg = rec_from_global(pp, pr, ps, k);
             const RecP q = inlds ? recp_from_lds(s_rec, c) : recp_of(qg);
@@ -1366,12 +1374,15 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     // One LDS block per wave: [SRT records: 64 x 64 B][region].  The region is the two 512-entry frontier / list arrays
     // (s_a, s_b); in the plain forward it is large enough to be re-used, after the traversal, as the per-ray crossing
     // table of the lane-independent sweep (kFastCross rows x 64 lanes x 4 B).
-    constexpr int kRegion = (!BWD && !WARP && kFastCross * kWave > 2 * kMaxList) ? kFastCross * kWave : 2 * kMaxList;
-    __shared__ __attribute__((aligned(16))) uint32_t smem[kRecSlots * 16 + kRegion];
+    // slot-synchronous layout: 64 records + s_a + s_b; lane-independent layout: kFastSlots records + kFastCross rows
+    constexpr int kSlowWords = kRecSlots * 16 + 2 * kMaxList;
+    constexpr int kFastWords = kFastSlots * 16 + kFastCross * kWave;
+    constexpr int kWords = (!BWD && !WARP && kFastWords > kSlowWords) ? kFastWords : kSlowWords;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[kWords];
     float4 *s_rec = reinterpret_cast<float4 *>(smem);
     int *s_a = reinterpret_cast<int *>(smem + kRecSlots * 16);
     int *s_b = s_a + kMaxList;
-    uint32_t *s_tab = smem + kRecSlots * 16;
+    uint32_t *s_tab = smem + kFastSlots * 16;
     if (BWD) {
         bool emit_all = p.fallback_all != 0;
         if (!emit_all) {  // nothing to do unless the forward raised a flag
