@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
 //   LDS: [V] float4 template slab | [4][Vp] int32 gradient "hi" | [4][Vp] uint32 gradient "lo" |
-//        [4][Vp] float drain target | ray queue (kQueueCap x 16 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
+//        ray queue (kQueueCap x 8 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
 //             COMPACTED into the LDS queue (ballot + popcount prefix inside the wave, one LDS integer atomic per
@@ -1443,13 +1443,20 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 //   4 = count same-address / same-bank lanes per 32-lane group into diag (tools/exp4_stats.py).
 #define MVP_EXP 0
 #endif
-constexpr int kPrimBlock = 256;
+// Waves per workgroup (one workgroup = one primitive) is a template parameter of the kernel, PW in {2, 3}.  The kernel is
+// latency-bound per workgroup and holds ~164 VGPRs (12 waves per CU): 3 waves x 4 workgroups per CU keeps one more
+// primitive in flight than round 1's 4 x 3, 2 waves x 5 workgroups two more.  Which is faster depends on how much work a
+// primitive has: K = 16384 at 512^2 (few packets per primitive) prefers 2 waves (C3 backward 0.87 -> 0.74 ms), K = 8192 at
+// 1024^2 prefers 3 (C4 1.90 vs 2.01 ms), C2 is indifferent; the host picks by packets per primitive.
 constexpr int kFixHiBits = 14;
 constexpr int kGradPadZ = 5;  // see the note on the gradient arrays above
 constexpr uint32_t kFixMaxSamples = 65536u;
-constexpr int kEntriesPerWave = 4;   // list entries (packets) each wave examines per round
-constexpr int kEntriesPerRound = 4 * kEntriesPerWave;  // typical lists (~10 entries at C2) finish in ONE round
-constexpr int kQueueCap = kEntriesPerRound * 64;       // rays per round
+#ifndef MVP_ENTRIES_PER_WAVE
+#define MVP_ENTRIES_PER_WAVE 5
+#endif
+constexpr int kEntriesPerWave = MVP_ENTRIES_PER_WAVE;  // list entries (packets) each wave examines per round
+__host__ __device__ constexpr int prim_entries_per_round(int pw) { return pw * kEntriesPerWave; }  // typical lists: ONE round
+__host__ __device__ constexpr int prim_queue_cap(int pw) { return prim_entries_per_round(pw) * 64; }  // rays per round
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
 
 // Backward prologue.  (1) Per ray packet (8x8 pixels): max |grad_rayrgba| -> pmax[packet] as float bits (non-negative
@@ -1514,8 +1521,10 @@ __device__ __forceinline__ float fix_value(int hi, uint32_t lo) {
 
 // TS > 0: the slab is TS^3 (compile-time strides: the 64 atomics and 8 reads of a sample share ONE address register and
 // use immediate offsets); TS == 0: any slab size, strides in registers.
-template <bool FADE8, int TS>
-__global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchParams p) {
+template <bool FADE8, int TS, int PW>
+__global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams p) {
+    constexpr int kPrimWaves = PW, kPrimBlock = PW * 64;
+    constexpr int kEntriesPerRound = prim_entries_per_round(PW), kQueueCap = prim_queue_cap(PW);
     const int TD = TS ? TS : p.TD, TH = TS ? TS : p.TH, TW = TS ? TS : p.TW;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int V = TD * TH * TW;
@@ -1524,9 +1533,9 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     float4 *s_T = smem4;
     int *s_hi = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar
     uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_hi + 4 * Vp);
-    float *s_gf = reinterpret_cast<float *>(s_lo + 4 * Vp);  // [4][Vp] float: receives the integer sums whenever the
-                                                             // per-slab sample count since the last drain nears 65536
-    uint4 *s_q = reinterpret_cast<uint4 *>(s_gf + 4 * Vp);  // 12*Vp words past a 16-byte aligned base
+    // (whenever the per-slab sample count since the last drain nears 65536 the integer sums are flushed into
+    //  grad_template itself -- every voxel has one owner thread -- and restart from zero)
+    uint2 *s_q = reinterpret_cast<uint2 *>(s_lo + 4 * Vp);  // 8*Vp words past a 16-byte aligned base
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
@@ -1558,8 +1567,13 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     q.r2 = mk3(cload(qr + 6), cload(qr + 7), cload(qr + 8));
     q.scale = mk3(cload(qs), cload(qs + 1), cload(qs + 2));
     const float4 *T4 = reinterpret_cast<const float4 *>(p.tplate) + pk * (size_t)V;
-    float4 tv0 = make_float4(0.f, 0.f, 0.f, 0.f), tv1 = tv0;
-    if (TS == 8) tv0 = T4[tid], tv1 = T4[tid + kPrimBlock];
+    constexpr int kVoxPerThread = (512 + kPrimBlock - 1) / kPrimBlock;  // 8^3 slab: voxels staged per thread
+    float4 tv[kVoxPerThread];
+    if (TS == 8) {
+#pragma unroll
+        for (int i = 0; i < kVoxPerThread; ++i)
+            tv[i] = (tid + i * kPrimBlock < 512) ? T4[tid + i * kPrimBlock] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
@@ -1570,9 +1584,11 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     if (!dead && cnt > 0u) {
         for (uint32_t e = tid; e < cnt; e += kPrimBlock) gbits = max(gbits, pmax_n[list[e].x >> 9]);
         if (TS == 8) {
-            s_T[tid] = tv0, s_T[tid + kPrimBlock] = tv1;
-            tmax = fmaxf(fmaxf(fmaxf(fabsf(tv0.x), fabsf(tv0.y)), fabsf(tv0.z)),
-                         fmaxf(fmaxf(fabsf(tv1.x), fabsf(tv1.y)), fabsf(tv1.z)));
+#pragma unroll
+            for (int i = 0; i < kVoxPerThread; ++i) {
+                if (tid + i * kPrimBlock < 512) s_T[tid + i * kPrimBlock] = tv[i];
+                tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(tv[i].x), fabsf(tv[i].y)), fabsf(tv[i].z)));
+            }
         } else {
             for (int v = tid; v < V; v += kPrimBlock) {
                 const float4 t = T4[v];
@@ -1595,9 +1611,10 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
     __syncthreads();
     float s_rgb = 0.f, s_a = 0.f;
     if (!dead && cnt > 0u) {
-        tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        gbits = max(max(__float_as_uint(s_red[4]), __float_as_uint(s_red[5])),
-                    max(__float_as_uint(s_red[6]), __float_as_uint(s_red[7])));
+        tmax = s_red[0], gbits = __float_as_uint(s_red[4]);
+#pragma unroll
+        for (int w = 1; w < kPrimWaves; ++w)
+            tmax = fmaxf(tmax, s_red[w]), gbits = max(gbits, __float_as_uint(s_red[4 + w]));
         const float G = gbits > 0x7f800000u ? INFINITY : __uint_as_float(gbits);  // NaN -> Inf -> handed over below
         const float Rmax = __uint_as_float(cload(tail + 2));
         // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
@@ -1658,7 +1675,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         // (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the
         // 64 rays a wave marches together have (nearly) the same number of steps.
         const uint32_t eend = min(cnt, ebase + (uint32_t)kEntriesPerRound);
-        uint4 item[kEntriesPerWave];
+        uint2 item[kEntriesPerWave];  // {ray index inside the image | list slot << 23, first step | steps << 16}
         uint32_t ticket[kEntriesPerWave];
         bool live2[kEntriesPerWave];
         bool toolong = false;
@@ -1668,7 +1685,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
             live2[u] = false;
             ticket[u] = 0u;
-            item[u] = make_uint4(0u, 0u, 0u, 0u);
+            item[u] = make_uint2(0u, 0u);
             if (e < eend) {
                 const uint32_t *lw = reinterpret_cast<const uint32_t *>(list + e);  // wave-uniform: scalar loads
                 const uint2 ent = make_uint2(cload(lw), cload(lw + 1));
@@ -1704,7 +1721,7 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
                     const int len = shi - slo + 1;
                     if (len > 127) toolong = true;
                     live2[u] = true;
-                    item[u] = make_uint4(r, (uint32_t)slo | ((uint32_t)len << 16), slot, 0u);
+                    item[u] = make_uint2(r | (slot << 23), (uint32_t)slo | ((uint32_t)len << 16));
                     ticket[u] = atomicAdd(s_bucket + min(len, kLenBuckets) - 1, 1u);
                     mylen += (uint32_t)len;
                 }
@@ -1756,15 +1773,28 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         // ---------------- drain the integer accumulators before they could overflow ----------------
         const uint32_t round_samples = s_qn[1];
         if (pending + round_samples > kFixMaxSamples) {
+            // (rare: > 65536 samples on one primitive.)  Every voxel is owned by one thread, here and at the end, so the
+            // partial sums can live in grad_template itself: written by the first drain, added to by later ones.
             const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
+            size_t pkd = pk;
             int td = tid;
-            asm volatile("; drain addresses are made here" : "+v"(td));
-            for (int v = td; v < 4 * Vp; v += kPrimBlock) {
-                const float inv = v < 3 * Vp ? i_rgb : i_a;
-                const float add = fix_value(s_hi[v], s_lo[v]) * inv;
-                s_gf[v] = drained ? s_gf[v] + add : add;
-                s_hi[v] = 0;
-                s_lo[v] = 0u;
+            asm volatile("; drain addresses are made here" : "+s"(pkd), "+v"(td));
+            float4 *gd = reinterpret_cast<float4 *>(p.grad_tplate) + pkd * (size_t)V;
+            for (int v = td; v < V; v += kPrimBlock) {
+                const int z = v / sD, rem = v - z * sD;
+                const int gv = z * gD + rem;
+                float4 g;
+                g.x = fix_value(s_hi[gv], s_lo[gv]) * i_rgb;
+                g.y = fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
+                g.z = fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
+                g.w = fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
+                if (drained) {
+                    const float4 o_ = gd[v];
+                    g.x += o_.x, g.y += o_.y, g.z += o_.z, g.w += o_.w;
+                }
+                gd[v] = g;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s_hi[c * Vp + gv] = 0, s_lo[c * Vp + gv] = 0u;
             }
             drained = true;
             pending = 0u;
@@ -1776,15 +1806,15 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
         // way, and 2 waves x 64 lanes issue half the instructions (VALU and LDS atomics) of 4 waves x 32 lanes.
         const int nq = (int)*s_qn;
         const int per = kWave;
-        for (int qb = wave * per; qb < nq; qb += 4 * per) {
+        for (int qb = wave * per; qb < nq; qb += kPrimWaves * per) {
             // queue neighbours are usually neighbouring pixels, i.e. rays in the same slab cell: put them in DIFFERENT
             // 32-lane halves so that their LDS atomics to the same address do not meet in one pass
             const int ql = ((lane & 31) << 1) | (lane >> 5);
             const bool have = ql < per && qb + ql < nq;
-            const uint4 it = have ? s_q[qb + ql] : make_uint4(0u, 0u, 0u, 0u);
-            const uint32_t r = it.x;  // index inside image n
+            const uint2 it = have ? s_q[qb + ql] : make_uint2(0u, 0u);
+            const uint32_t r = it.x & 0x7fffffu;  // index inside image n
             const int slo = (int)(it.y & 0xffffu), len = have ? (int)(it.y >> 16) : 0;
-            const uint32_t slot = it.z;
+            const uint32_t slot = it.x >> 23;
             f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
             float tmin = 0.f;
             f3 dL3 = mk3(0.f, 0.f, 0.f), rsat = mk3(-1.f, -1.f, -1.f);
@@ -2055,14 +2085,19 @@ __global__ __launch_bounds__(kPrimBlock, 3) void bwd_prim_kernel(const MarchPara
             g.y = fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
             g.z = fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
             g.w = fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
-            if (drained) {  // (workgroup-uniform) earlier drains, in the order they happened
-                g.x = s_gf[gv] + g.x, g.y = s_gf[Vp + gv] + g.y;
-                g.z = s_gf[2 * Vp + gv] + g.z, g.w = s_gf[3 * Vp + gv] + g.w;
+            if (drained) {  // (workgroup-uniform) earlier drains sit in grad_template already; same owner thread
+                const float4 o_ = gT4l[v];
+                g.x = o_.x + g.x, g.y = o_.y + g.y, g.z = o_.z + g.z, g.w = o_.w + g.w;
             }
             gT4l[v] = g;
         }
     }
-    if (tl < 12) s_red[48 + tl] = s_red[tl] + s_red[12 + tl] + s_red[24 + tl] + s_red[36 + tl];
+    if (tl < 12) {
+        float t_ = s_red[tl];
+#pragma unroll
+        for (int w = 1; w < kPrimWaves; ++w) t_ += s_red[w * 12 + tl];
+        s_red[48 + tl] = t_;
+    }
     __syncthreads();
     if (tl < 15) {
         const float *Rg = p.primrot + pkl * 9, *sg = p.primscale + pkl * 3;
@@ -2258,9 +2293,15 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
     const size_t Vp = (size_t)TD * ((size_t)TH * TW + kGradPadZ);
     // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
-    const size_t lds = V * 16 + Vp * 48 + (size_t)kQueueCap * 16 + 64 * sizeof(float) + 16 + kLenBuckets * 4;
+    // 2 or 3 waves per workgroup by the work a primitive has: ray packets per primitive (see the note at kEntriesPerWave)
+    const int pw = ((long long)p.tiles_x * p.tiles_y * 4 > 5ll * K) ? 3 : 2;
+    size_t lds = V * 16 + Vp * 32 + (size_t)prim_queue_cap(pw) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4;
+#ifdef MVP_DEBUG_HOOKS
+    if (const char *e = getenv("MVP_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiments: fewer workgroups per CU
+#endif
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
-    const bool prim_path = !norays && have_lists && lds <= 64 * 1024 && warp == nullptr;
+    // (queue items carry the ray index inside the image in 23 bits)
+    const bool prim_path = !norays && have_lists && lds <= 64 * 1024 && warp == nullptr && (long long)H * W <= (1ll << 23);
     const bool fade8 = fadeexp == 8.0f;
     if (!prim_path) {  // ray-centric backward owns everything: it accumulates, so zero-fill first
         hipError_t e = hipMemsetAsync(grad_tplate, 0, sizeof(float) * 4 * V * (size_t)N * K, st);
@@ -2282,16 +2323,24 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
                            p.pl_count + (size_t)N * K + 3, p.pl_count, (size_t)N * K, p.pl_count + (size_t)N * K);
         rc = launch_status();
         if (rc != MVP_OK) return rc;
-        const dim3 grid((unsigned)pb), block(kPrimBlock);
+        const dim3 grid((unsigned)pb), block((unsigned)pw * 64);
         const bool cube8 = TD == 8 && TH == 8 && TW == 8;  // the reference's slab size (and BASELINE's)
+#define MVP_LAUNCH_PRIM(F8_, TS_)                                                                  \
+    {                                                                                              \
+        if (pw == 3)                                                                               \
+            hipLaunchKernelGGL((bwd_prim_kernel<F8_, TS_, 3>), grid, block, lds, st, p);           \
+        else                                                                                       \
+            hipLaunchKernelGGL((bwd_prim_kernel<F8_, TS_, 2>), grid, block, lds, st, p);           \
+    }
         if (fade8 && cube8)
-            hipLaunchKernelGGL((bwd_prim_kernel<true, 8>), grid, block, lds, st, p);
+            MVP_LAUNCH_PRIM(true, 8)
         else if (fade8)
-            hipLaunchKernelGGL((bwd_prim_kernel<true, 0>), grid, block, lds, st, p);
+            MVP_LAUNCH_PRIM(true, 0)
         else if (cube8)
-            hipLaunchKernelGGL((bwd_prim_kernel<false, 8>), grid, block, lds, st, p);
+            MVP_LAUNCH_PRIM(false, 8)
         else
-            hipLaunchKernelGGL((bwd_prim_kernel<false, 0>), grid, block, lds, st, p);
+            MVP_LAUNCH_PRIM(false, 0)
+#undef MVP_LAUNCH_PRIM
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         p.fallback_all = 0;
