@@ -1844,8 +1844,19 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
 #if MVP_EXP == 2
             int exp_sink = 0;
 #endif
+#ifndef MVP_NO_STEP_ROTATION
+            // Queue neighbours are neighbouring pixels: at the same step index they sit in the same slab cell and their
+            // 64 atomics hit the same addresses (serialised by the LDS).  The samples of a ray are independent here
+            // (the forward recorded where the ray saturated), so each lane walks its steps from a different starting
+            // offset, wrapping around: neighbours are then at different depths at any one time.
+            int rot = have ? (int)(((uint32_t)ql * 5u) & 7u) : 0;
+            while (rot >= len && len > 0) rot -= len;
+#else
+            const int rot = 0;
+#endif
             for (int st = 0; st < nsteps; ++st) {
-                const int s = slo + st;
+                const int so = st + rot;
+                const int s = slo + (so >= len ? so - len : so);
                 const float t = fmaf((float)s, dt, tmin);
                 const f3 x = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
                 const f3 xmt = x - q.pos;

