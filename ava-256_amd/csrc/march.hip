@@ -1449,7 +1449,10 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // primitive has: K = 16384 at 512^2 (few packets per primitive) prefers 2 waves (C3 backward 0.87 -> 0.74 ms), K = 8192 at
 // 1024^2 prefers 3 (C4 1.90 vs 2.01 ms), C2 is indifferent; the host picks by packets per primitive.
 constexpr int kFixHiBits = 14;
-constexpr int kGradPadZ = 5;  // see the note on the gradient arrays above
+#ifndef MVP_GRADPAD
+#define MVP_GRADPAD 5
+#endif
+constexpr int kGradPadZ = MVP_GRADPAD;  // see the note on the gradient arrays above
 constexpr uint32_t kFixMaxSamples = 65536u;
 #ifndef MVP_ENTRIES_PER_WAVE
 #define MVP_ENTRIES_PER_WAVE 5
@@ -1849,7 +1852,11 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
             // 64 atomics hit the same addresses (serialised by the LDS).  The samples of a ray are independent here
             // (the forward recorded where the ray saturated), so each lane walks its steps from a different starting
             // offset, wrapping around: neighbours are then at different depths at any one time.
-            int rot = have ? (int)(((uint32_t)ql * 5u) & 7u) : 0;
+#ifndef MVP_ROT_MUL
+#define MVP_ROT_MUL 5u
+#define MVP_ROT_MASK 7u
+#endif
+            int rot = have ? (int)(((uint32_t)ql * MVP_ROT_MUL) & MVP_ROT_MASK) : 0;
             while (rot >= len && len > 0) rot -= len;
 #else
             const int rot = 0;
