@@ -42,15 +42,18 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     s = make_scene(N, H, W, K, device="cuda", seed=5 + K, alpha_gain=again)
     diag = torch.zeros(8, dtype=torch.int32, device="cuda")
     _hooks.set_diag_buffer(diag)
-    rgba1, sat1, cnt1, _ = _forward_with_handoff(ops, s)
+    gout = torch.randn(N, H, W, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    rgba1, sat1, cnt1, t1 = _forward_with_handoff(ops, s)
     d1 = _hooks.read_diag()
     assert d1["packets_hit"] > 0 and d1["slowpath_packets"] < d1["packets_hit"], d1   # the fast sweep really ran
+    rgba1.backward(gout)
     diag.zero_()
     os.environ["MVP_DEBUG_SLOT_SWEEP"] = "1"
     _lib.use_library(DBG_LIB)
     try:
-        rgba2, sat2, cnt2, _ = _forward_with_handoff(ops, s)
+        rgba2, sat2, cnt2, t2 = _forward_with_handoff(ops, s)
         d2 = _hooks.read_diag()
+        rgba2.backward(gout)
     finally:
         del os.environ["MVP_DEBUG_SLOT_SWEEP"]
         _lib.use_library(None)
@@ -59,6 +62,12 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     assert torch.equal(rgba1, rgba2)
     assert torch.equal(sat1, sat2)
     assert torch.equal(cnt1[: N * K], cnt2[: N * K])
+    # ... and the backward over either hand-off: same samples; the slab gradient is an integer sum (order-free, so
+    # bit-identical although the two forwards append list entries in different orders), pose gradients are fp32 sums.
+    assert torch.equal(t1["template"].grad, t2["template"].grad)
+    for k in ("primpos", "primrot", "primscale"):
+        g1, g2 = t1[k].grad, t2[k].grad
+        assert float((g1 - g2).abs().max()) <= 1e-4 * float(g2.abs().max()), k
 
 
 @pytest.mark.parametrize("mode", BACKWARD_MODES)
