@@ -89,6 +89,7 @@ struct MarchParams {
     uint2 *pl_list;       // [N*K, pl_cap]: {(packet << 9) | list slot, lo | hi << 16}
     int pl_cap;
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
+    int prim_lds_base;    // bwd_prim_kernel<.., WARP>: byte offset of the warp-field arrays in its dynamic LDS
     int total_packets;    // 8 * chunk * N
     // Only read by builds with -DMVP_DEBUG_HOOKS (tools/exp_variants.sh); the product library ignores the environment.
     int debug_force_dfs;  // MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
@@ -1524,8 +1525,11 @@ __device__ __forceinline__ float fix_value(int hi, uint32_t lo) {
 
 // TS > 0: the slab is TS^3 (compile-time strides: the 64 atomics and 8 reads of a sample share ONE address register and
 // use immediate offsets); TS == 0: any slab size, strides in registers.
-template <bool FADE8, int TS, int PW>
-__global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams p) {
+// WARP: the warp-field sampler (algo 1, primsampler.h:53-58,82-88): a second LDS slab (the warp grid) and a second set of
+// fixed-point accumulators (grad_warp); the template is sampled at warp(y) with zero padding (general strides only).
+template <bool FADE8, int TS, int PW, bool WARP = false>
+__global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const MarchParams p) {
+    static_assert(!WARP || TS == 0, "the warp-field variant uses run-time slab dimensions");
     constexpr int kPrimWaves = PW, kPrimBlock = PW * 64;
     constexpr int kEntriesPerRound = prim_entries_per_round(PW), kQueueCap = prim_queue_cap(PW);
     const int TD = TS ? TS : p.TD, TH = TS ? TS : p.TH, TW = TS ? TS : p.TW;
@@ -1542,6 +1546,13 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
+    // WARP: [warp grid as float4 (x,y,z,-)][3][VWp] hi, [3][VWp] lo -- behind everything else (16-byte aligned: the
+    // host sizes the part above as a multiple of 16 bytes)
+    const int WD = WARP ? p.WD : 2, WH = WARP ? p.WH : 2, WW = WARP ? p.WW : 2;
+    const int VW = WD * WH * WW, gHw = WW, gDw = WH * WW + kGradPadZ, VWp = WD * gDw;
+    float4 *s_W = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem4) + p.prim_lds_base);
+    int *s_whi = reinterpret_cast<int *>(s_W + VW);
+    uint32_t *s_wlo = reinterpret_cast<uint32_t *>(s_whi + 3 * VWp);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int K = p.K;
@@ -1582,10 +1593,15 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
 
     // ---- stage the slab and its max |rgb|; bound of the upstream gradient over the packets on the list ----
-    float tmax = 0.f;
+    float tmax = 0.f, amax = 0.f;  // amax (max |opacity|): only the warp-field bound needs it
     uint32_t gbits = 0u;
     if (!dead && cnt > 0u) {
         for (uint32_t e = tid; e < cnt; e += kPrimBlock) gbits = max(gbits, pmax_n[list[e].x >> 9]);
+        if constexpr (WARP) {
+            const float *Wg = p.warp + pk * (size_t)VW * 3;
+            for (int v = tid; v < VW; v += kPrimBlock) s_W[v] = make_float4(Wg[v * 3], Wg[v * 3 + 1], Wg[v * 3 + 2], 0.f);
+            for (int v = tid; v < 3 * VWp; v += kPrimBlock) s_whi[v] = 0, s_wlo[v] = 0u;
+        }
         if (TS == 8) {
 #pragma unroll
             for (int i = 0; i < kVoxPerThread; ++i) {
@@ -1597,6 +1613,7 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
                 const float4 t = T4[v];
                 s_T[v] = t;
                 tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
+                if constexpr (WARP) amax = fmaxf(amax, fabsf(t.w));
             }
         }
         // hi and lo are adjacent (8 * Vp words from a 16-byte aligned base): 16-byte stores.  The float drain target is
@@ -1610,21 +1627,35 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
         tmax = wave_max(tmax);
         gbits = (uint32_t)wave_max((int)gbits);
         if (lane == 0) s_red[wave] = tmax, s_red[4 + wave] = __uint_as_float(gbits);
+        if constexpr (WARP) {
+            amax = wave_max(amax);
+            if (lane == 0) s_red[8 + wave] = amax;
+        }
     }
     __syncthreads();
-    float s_rgb = 0.f, s_a = 0.f;
+    float s_rgb = 0.f, s_a = 0.f, s_w = 0.f;
     if (!dead && cnt > 0u) {
         tmax = s_red[0], gbits = __float_as_uint(s_red[4]);
 #pragma unroll
         for (int w = 1; w < kPrimWaves; ++w)
             tmax = fmaxf(tmax, s_red[w]), gbits = max(gbits, __float_as_uint(s_red[4 + w]));
+        if constexpr (WARP) {
+            amax = s_red[8];
+#pragma unroll
+            for (int w = 1; w < kPrimWaves; ++w) amax = fmaxf(amax, s_red[8 + w]);
+        }
         const float G = gbits > 0x7f800000u ? INFINITY : __uint_as_float(gbits);  // NaN -> Inf -> handed over below
         const float Rmax = __uint_as_float(cload(tail + 2));
         // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
         const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
+        // WARP: a corner of the warp grid receives w_c * dL/dy1, |w_c| <= 1 and dL/dy1_x = (TW-1)/2 * sum over corners of
+        // +-w_y w_z (value_c . dLs) with sum |w_y w_z| <= 2, |value_c . dLs| <= 3 Tmax G + Amax Ba
+        float Bw = 1.f;
+        if constexpr (WARP)
+            Bw = (float)(max(TD, max(TH, TW)) - 1) * (3.f * tmax * Brgb + amax * Ba);
         if (G == 0.f) {
             s_rgb = s_a = -1.f;  // all-zero upstream gradient on every listed packet: outputs are zero
-        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f)) {
+        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f) || !(Bw < 1.0e30f)) {
             dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
             if (tid == 0) {
                 atomicOr(p.pl_count + pk, kCountDead);
@@ -1633,10 +1664,15 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
         } else {
             s_rgb = fix_scale(Brgb) * 65536.f;  // value -> int(value * s): 16 fractional bits
             s_a = fix_scale(Ba) * 65536.f;
+            if constexpr (WARP) s_w = fix_scale(fmaxf(Bw, 1.0e-30f)) * 65536.f;
         }
     }
     __syncthreads();  // s_red is reused below
     if (cnt == 0u || dead || s_rgb < 0.f) {  // this launch doubles as the zero-fill of the gradient buffers
+        if constexpr (WARP) {
+            float *gW = p.grad_warp + pk * (size_t)VW * 3;
+            for (int v = tid; v < VW * 3; v += kPrimBlock) gW[v] = 0.f;
+        }
         for (int v = tid; v < V; v += kPrimBlock) gT4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < 9) p.grad_primrot[pk * 9 + tid] = 0.f;
         if (tid < 3) p.grad_primscale[pk * 3 + tid] = 0.f;
@@ -1739,7 +1775,8 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
         // a ray crosses this box over more than 127 steps, a sample weight left [-1, 1] in an earlier round (signed
         // opacity), or the round alone would add more samples than the integer accumulators can take between two
         // drains: not this kernel's case
-        if (s_qn[2] != 0u || s_qn[1] > kFixMaxSamples) {
+        // (WARP: no mid-way drain of the second accumulator set -- such a primitive is handed over as a whole)
+        if (s_qn[2] != 0u || s_qn[1] > kFixMaxSamples || (WARP && pending + s_qn[1] > kFixMaxSamples)) {
             if (tid == 0) {
                 atomicOr(p.pl_count + pk, kCountDead);
                 raise_flag(tail, kFlagBwdHandoff);
@@ -1750,6 +1787,10 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
             int tz = tid;
             asm volatile("; zero-fill exit" : "+s"(pkz), "+v"(tz));
             float4 *gz = reinterpret_cast<float4 *>(p.grad_tplate) + pkz * (size_t)V;
+            if constexpr (WARP) {
+                float *gW = p.grad_warp + pkz * (size_t)VW * 3;
+                for (int v = tz; v < VW * 3; v += kPrimBlock) gW[v] = 0.f;
+            }
             for (int v = tz; v < V; v += kPrimBlock) gz[v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tz < 9) p.grad_primrot[pkz * 9 + tz] = 0.f;
             if (tz < 3) p.grad_primscale[pkz * 3 + tz] = 0.f;
@@ -1908,6 +1949,102 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
                         ex_bank[h] += (uint32_t)(uni(wave_max(lane < 32 ? nb[h] : 0)) + uni(wave_max(lane < 32 ? 0 : nb[h])));
                 }
 #endif
+                if constexpr (WARP) {
+                    // ---- warp-field sampler (primsampler.h:68-91 with dowarp; utils.h:504-643 twice) ----
+                    if (inside) {
+                        const float fade = fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                        f3 ypow;
+                        if (FADE8) {
+                            const f3 y2 = y * y, y4 = y2 * y2;
+                            ypow = y4 * y2 * y;
+                        } else {
+                            const float e1 = p.fadeexp - 1.f;
+                            ypow = mk3(fast_pow(fabsf(y.x), e1) * (y.x > 0.f ? 1.f : -1.f),
+                                       fast_pow(fabsf(y.y), e1) * (y.y > 0.f ? 1.f : -1.f),
+                                       fast_pow(fabsf(y.z), e1) * (y.z > 0.f ? 1.f : -1.f));
+                        }
+                        const TriG tw = tri_general(y, WD, WH, WW);  // y strictly inside: all 8 corners in bounds
+                        f3 y1 = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            int vox;
+                            float w;
+                            if (tri_inb(tw, c, WD, WH, WW, vox, w)) {
+                                const float4 qw = s_W[vox];
+                                y1.x += qw.x * w, y1.y += qw.y * w, y1.z += qw.z * w;
+                            }
+                        }
+                        const TriG tt = tri_general(y1, TD, TH, TW);  // may leave the slab: zero padding
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            int vox;
+                            float w;
+                            if (tri_inb(tt, c, TD, TH, TW, vox, w)) {
+                                const float4 qv = s_T[vox];
+                                v.x += qv.x * w, v.y += qv.y * w, v.z += qv.z * w, v.w += qv.w * w;
+                            }
+                        }
+                        const float alpha = v.w * fade;
+                        const bool issat = key == satkey;
+                        const float weight = issat ? (1.f - wbefore) : alpha * dt;
+                        wbad = wbad || !(fabsf(weight) <= 1.0f);
+                        float4 dLs;
+                        dLs.x = weight * dL3.x;
+                        dLs.y = weight * dL3.y;
+                        dLs.z = weight * dL3.z;
+                        dLs.w = issat ? 0.f
+                                      : dt * ((v.x - (has_sat ? rsat.x : 0.f)) * dL3.x +
+                                              (v.y - (has_sat ? rsat.y : 0.f)) * dL3.y +
+                                              (v.z - (has_sat ? rsat.z : 0.f)) * dL3.z + (has_sat ? 0.f : dLw));
+                        const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
+                        f3 gy = ypow * gf;
+                        dLs.w *= fade;
+#define MVP_FIXW(HI_, LO_, IDX_, VAL_)                              \
+    {                                                               \
+        const int t_ = fix_rn(VAL_);                                \
+        atomicAdd((HI_) + (IDX_), t_ >> 16);                        \
+        atomicAdd((LO_) + (IDX_), (uint32_t)t_);                    \
+    }
+                        f3 gi1 = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            int vox;
+                            float w;
+                            if (tri_inb(tt, c, TD, TH, TW, vox, w)) {
+                                const float4 qv = s_T[vox];
+                                const int gv = (tt.z0 + (c >> 2)) * gD + (tt.y0 + ((c >> 1) & 1)) * gH + tt.x0 + (c & 1);
+                                MVP_FIXW(s_hi, s_lo, gv, w * dLs.x * s_rgb)
+                                MVP_FIXW(s_hi, s_lo, Vp + gv, w * dLs.y * s_rgb)
+                                MVP_FIXW(s_hi, s_lo, 2 * Vp + gv, w * dLs.z * s_rgb)
+                                MVP_FIXW(s_hi, s_lo, 3 * Vp + gv, w * dLs.w * s_a)
+                                tri_posgrad_acc(tt, c, qv.x * dLs.x + qv.y * dLs.y + qv.z * dLs.z + qv.w * dLs.w, gi1);
+                            }
+                        }
+                        const f3 g1 = mk3(mx * gi1.x, my * gi1.y, mz * gi1.z);  // dL/dy1
+                        f3 gi0 = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            int vox;
+                            float w;
+                            if (tri_inb(tw, c, WD, WH, WW, vox, w)) {
+                                const float4 qw = s_W[vox];
+                                const int gv = (tw.z0 + (c >> 2)) * gDw + (tw.y0 + ((c >> 1) & 1)) * gHw + tw.x0 + (c & 1);
+                                MVP_FIXW(s_whi, s_wlo, gv, w * g1.x * s_w)
+                                MVP_FIXW(s_whi, s_wlo, VWp + gv, w * g1.y * s_w)
+                                MVP_FIXW(s_whi, s_wlo, 2 * VWp + gv, w * g1.z * s_w)
+                                tri_posgrad_acc(tw, c, qw.x * g1.x + qw.y * g1.y + qw.z * g1.z, gi0);
+                            }
+                        }
+#undef MVP_FIXW
+                        gy.x += 0.5f * (float)(WW - 1) * gi0.x;
+                        gy.y += 0.5f * (float)(WH - 1) * gi0.y;
+                        gy.z += 0.5f * (float)(WD - 1) * gi0.z;
+                        ra0 += gy.x, ra1 += gy.y, ra2 += gy.z;
+                        rb0 = fmaf(t, gy.x, rb0), rb1 = fmaf(t, gy.y, rb1), rb2 = fmaf(t, gy.z, rb2);
+                    }
+                    continue;
+                }
                 if (inside) {
                     float fade;
                     f3 ypow;
@@ -2087,6 +2224,10 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
             atomicOr(p.pl_count + pkl, kCountDead);
             raise_flag(p.pl_count + (size_t)p.N * K, kFlagBwdHandoff);
         }
+        if constexpr (WARP) {
+            float *gW = p.grad_warp + pkl * (size_t)VW * 3;
+            for (int v = tl; v < VW * 3; v += kPrimBlock) gW[v] = 0.f;
+        }
         for (int v = tl; v < V; v += kPrimBlock) gT4l[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tl < 9) p.grad_primrot[pkl * 9 + tl] = 0.f;
         if (tl < 3) p.grad_primscale[pkl * 3 + tl] = 0.f;
@@ -2108,6 +2249,17 @@ __global__ __launch_bounds__(PW * 64, 3) void bwd_prim_kernel(const MarchParams 
                 g.x = o_.x + g.x, g.y = o_.y + g.y, g.z = o_.z + g.z, g.w = o_.w + g.w;
             }
             gT4l[v] = g;
+        }
+    }
+    if constexpr (WARP) {  // grad_warp, written exactly once
+        const float i_w = 1.0f / s_w;
+        float *gW = p.grad_warp + pkl * (size_t)VW * 3;
+        const int sDw = WH * WW;
+        for (int v = tl; v < VW; v += kPrimBlock) {
+            const int z = v / sDw, rem = v - z * sDw;
+            const int gv = z * gDw + rem;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gW[v * 3 + j] = fix_value(s_whi[j * VWp + gv], s_wlo[j * VWp + gv]) * i_w;
         }
     }
     if (tl < 12) {
@@ -2198,7 +2350,6 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
     p.WD = WD, p.WH = WH, p.WW = WW, p.warp = warp;
     if (warp && (WD < 2 || WH < 2 || WW < 2)) return MVP_ERR_UNSUPPORTED;
-    if (warp) rayaux = nullptr, primlist_count = nullptr, primlist = nullptr;  // algo 1: ray-centric backward only
     p.stepsize = stepsize, p.fadescale = fadescale, p.fadeexp = fadeexp;
     p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
     p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
@@ -2314,12 +2465,18 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     // 2 or 3 waves per workgroup by the work a primitive has: ray packets per primitive (see the note at kEntriesPerWave)
     const int pw = ((long long)p.tiles_x * p.tiles_y * 4 > 5ll * K) ? 3 : 2;
     size_t lds = V * 16 + Vp * 32 + (size_t)prim_queue_cap(pw) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4;
+    if (warp) {  // + the warp grid (float4 per node) and its 2 x [3][VWp] accumulators
+        lds = (lds + 15) & ~(size_t)15;
+        p.prim_lds_base = (int)lds;
+        const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + kGradPadZ);
+        lds += VW * 16 + VWp * 24;
+    }
 #ifdef MVP_DEBUG_HOOKS
     if (const char *e = getenv("MVP_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiments: fewer workgroups per CU
 #endif
     const bool have_lists = rayaux && primlist_count && primlist && primlist_cap > 0;
     // (queue items carry the ray index inside the image in 23 bits)
-    const bool prim_path = !norays && have_lists && lds <= 64 * 1024 && warp == nullptr && (long long)H * W <= (1ll << 23);
+    const bool prim_path = !norays && have_lists && lds <= 64 * 1024 && (long long)H * W <= (1ll << 23);
     const bool fade8 = fadeexp == 8.0f;
     if (!prim_path) {  // ray-centric backward owns everything: it accumulates, so zero-fill first
         hipError_t e = hipMemsetAsync(grad_tplate, 0, sizeof(float) * 4 * V * (size_t)N * K, st);
@@ -2350,7 +2507,18 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         else                                                                                       \
             hipLaunchKernelGGL((bwd_prim_kernel<F8_, TS_, 2>), grid, block, lds, st, p);           \
     }
-        if (fade8 && cube8)
+#define MVP_LAUNCH_PRIMW(F8_)                                                                      \
+    {                                                                                              \
+        if (pw == 3)                                                                               \
+            hipLaunchKernelGGL((bwd_prim_kernel<F8_, 0, 3, true>), grid, block, lds, st, p);       \
+        else                                                                                       \
+            hipLaunchKernelGGL((bwd_prim_kernel<F8_, 0, 2, true>), grid, block, lds, st, p);       \
+    }
+        if (warp && fade8)
+            MVP_LAUNCH_PRIMW(true)
+        else if (warp)
+            MVP_LAUNCH_PRIMW(false)
+        else if (fade8 && cube8)
             MVP_LAUNCH_PRIM(true, 8)
         else if (fade8)
             MVP_LAUNCH_PRIM(true, 0)
@@ -2359,6 +2527,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         else
             MVP_LAUNCH_PRIM(false, 0)
 #undef MVP_LAUNCH_PRIM
+#undef MVP_LAUNCH_PRIMW
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         p.fallback_all = 0;

@@ -116,7 +116,7 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
     pl_cap = 0
     if gradmode:
         raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
-        if not _hooks.force_ray_centric_backward and warp is None:
+        if not _hooks.force_ray_centric_backward:
             # hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record
             # and, per primitive, the list of ray packets that touch it
             pl_cap = primlist_capacity(H, W, K)

@@ -75,7 +75,7 @@ def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildre
     raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
     rayaux = pl_count = pl_list = None
     pl_cap = 0
-    if raysat is not None and warp is None:
+    if raysat is not None:
         pl_cap = primlist_capacity(H, W, K)
         rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
         pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)

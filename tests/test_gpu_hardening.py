@@ -128,6 +128,55 @@ def test_signed_opacity(ops, oracle64, mode):
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "signed alpha " + mode)
 
 
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+def test_warp_field_with_signed_opacity(ops, oracle64, mode):
+    """The warp-field variant of the primitive-centric backward has a second set of fixed-point accumulators
+    (grad_warp) scaled from the same bounds; a weight outside [-1, 1] (signed opacity) must hand the primitive over
+    with BOTH slab gradients zero-filled, and the ray-centric kernel must then produce them (fp32 atomics)."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 64, 64, 256
+    s = make_scene(N, H, W, K, device="cpu", seed=34, alpha_gain=1.0)
+    g = torch.Generator().manual_seed(3)
+    tpl = s["template"].clone()
+    tpl[..., 3] = 120.0 * torch.randn(N, K, 1, 1, 1, generator=g).expand(N, K, 8, 8, 8) + 20.0 * torch.randn(N, K, 8, 8, 8, generator=g)
+    lin = torch.linspace(-1.0, 1.0, 5)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    warp = (torch.stack([xx, yy, zz], dim=-1)[None, None] + 0.1 * torch.randn(N, K, 5, 5, 5, 3, generator=g)).contiguous().numpy()
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), tpl.numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, warp=warp, ray_diagnostics=True)
+    assert ref_rgba[..., 3].min() < -0.2 and st["rays_saturated"] > 50
+    gout = np.random.default_rng(7).normal(size=ref_rgba.shape)
+    fragile = FragileRays(ref_sat, st["margin"], gout, max_frac=0.01, min_allowed=4)
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode, warp=warp)
+    rgp, rgr, rgs, rgt, rgw = oracle64.march_backward(*a, ref_sat, fragile.masked(), warp=warp)
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "signed alpha + warp " + mode)
+    gw = grads["warp"]
+    assert cosine(gw, rgw) >= 0.9999 and np.linalg.norm(gw - rgw) <= 1e-2 * np.linalg.norm(rgw)
+
+
+def test_warp_field_backward_is_reproducible(ops):
+    """grad_template and grad_warp of the primitive-centric kernel are integer sums: two runs give the same bits."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 2, 96, 96, 512
+    s = make_scene(N, H, W, K, device="cuda", seed=12, alpha_gain=3.0)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    lin = torch.linspace(-1.0, 1.0, 8, device="cuda")
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    warp0 = (torch.stack([xx, yy, zz], dim=-1)[None, None] + 0.1 * torch.randn(N, K, 8, 8, 8, 3, device="cuda", generator=g)).contiguous()
+    gout = torch.randn(N, H, W, 4, device="cuda", generator=g)
+    rp, rd, tm = ops.compute_raydirs(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"], s["volradius"])
+    res = []
+    for _ in range(2):
+        tpl = s["template"].clone().requires_grad_(True)
+        w = warp0.clone().requires_grad_(True)
+        rgba = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (s["primpos"], s["primrot"], s["primscale"]), tpl, w, algo=1)
+        rgba.backward(gout)
+        res.append((tpl.grad.clone(), w.grad.clone()))
+    assert float(res[0][1].abs().max()) > 0
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_backward_twice_over_one_forward(ops):
     """retain_graph / several losses: the backward marks things in the forward's hand-off buffer (primitives it hands
     to the ray-centric kernel) and derives its fixed-point scales from the upstream gradient of THAT call.  A second

@@ -222,13 +222,15 @@ def test_randomized_configurations(ops, oracle64, seed):
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), cfg)
 
 
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
 @pytest.mark.parametrize("name", ["march_warp_k8_m8", "march_warp_k8_m8_sat"])
-def test_warp_sampler_matches_reference_golden(ops, name):
-    """algo 1 (PrimSamplerTW<true>): fixtures from the reference's gradcheck(dowarp=True) dense loop (float64)."""
+def test_warp_sampler_matches_reference_golden(ops, name, mode):
+    """algo 1 (PrimSamplerTW<true>): fixtures from the reference's gradcheck(dowarp=True) dense loop (float64).
+    Backward by the primitive-centric kernel's warp-field variant, the ray-centric kernel, and both (cap4)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     rgba, grads, diag = _march(ops, g["raypos"], g["raydir"], g["stepsize"], g["tminmax"], g["primpos"],
                                g["primrot"], g["primscale"], g["template"], g["fadescale"], g["fadeexp"],
-                               grad_out=np.ones_like(g["rgba"]), warp=g["warp"])
+                               grad_out=np.ones_like(g["rgba"]), warp=g["warp"], mode=mode)
     assert np.abs(rgba - g["rgba"]).max() <= FWD_TOL * max(1.0, np.abs(g["rgba"]).max())
     mine = dict(template=grads["template"] * g["chain_template"], primpos=grads["primpos"] * g["chain_primpos"],
                 primrot=grads["primrot"], primscale=grads["primscale"] * g["chain_primscale"])
@@ -239,35 +241,46 @@ def test_warp_sampler_matches_reference_golden(ops, name):
     assert cosine(gw, rw) >= POSE_COS and np.abs(gw - rw).max() <= POSE_TOL * np.abs(rw).max()
 
 
-def test_warp_sampler_matches_oracle_on_a_shell_scene(ops, oracle64):
-    """Warp field = identity grid + noise on a 4^3 grid, production fade, ragged image, K not a power of two."""
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+@pytest.mark.parametrize("wshape,noise,fadescale,fadeexp,gw_maxabs", [((4, 4, 4), 0.15, 8.0, 8.0, 1e-1),
+                                                                     ((3, 5, 2), 0.6, 6.0, 5.0, 1e-1),
+                                                                     ((8, 8, 8), 0.3, 8.0, 8.0, 2e-1)],
+                         ids=["w4_n0.15", "w3x5x2_n0.6_fade5", "w8_n0.3"])
+def test_warp_sampler_matches_oracle_on_a_shell_scene(ops, oracle64, wshape, noise, fadescale, fadeexp, gw_maxabs, mode):
+    """Warp field = identity grid + noise, ragged image, K not a power of two.  Grids: cubic 4^3, non-cubic 3x5x2 with the
+    general fade and a warp strong enough that warped coordinates leave the slab (zero padding, utils.h:475-498), and the
+    8^3 grid of the reference's gradcheck.  Every owner of the backward (primitive-centric warp variant, ray-centric
+    kernel, mixed) must match the float64 oracle, grad_warp included."""
     from ava256_amd.scene import make_scene
     N, H, W, K = 2, 45, 52, 300
     s = make_scene(N, H, W, K, device="cpu", seed=21, alpha_gain=4.0)
     g = torch.Generator().manual_seed(5)
-    lin = torch.linspace(-1.0, 1.0, 4)
-    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    WD, WH, WW = wshape
+    zz, yy, xx = torch.meshgrid(torch.linspace(-1.0, 1.0, WD), torch.linspace(-1.0, 1.0, WH), torch.linspace(-1.0, 1.0, WW),
+                                indexing="ij")
     ident = torch.stack([xx, yy, zz], dim=-1)                                  # warp[z,y,x] = (x,y,z): identity
-    warp = (ident[None, None] + 0.15 * torch.randn(N, K, 4, 4, 4, 3, generator=g)).contiguous().numpy()
+    warp = (ident[None, None] + noise * torch.randn(N, K, WD, WH, WW, 3, generator=g)).contiguous().numpy()
     rp, rd, tm = scene_rays(oracle64, s)
     a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(),
          s["template"].numpy())
-    ref_rgba, ref_sat, st = oracle64.march_forward(*a, warp=warp, ray_diagnostics=True)
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, warp=warp, fadescale=fadescale, fadeexp=fadeexp, ray_diagnostics=True)
     gout = np.random.default_rng(8).normal(size=ref_rgba.shape)
     fragile = FragileRays(ref_sat, st["margin"], gout)
-    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, warp=warp)
+    rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, warp=warp, mode=mode)
     fr = fragile.mask
     g2 = fragile.masked()
-    rgp, rgr, rgs, rgt, rgw = oracle64.march_backward(*a, ref_sat, g2, warp=warp)
+    rgp, rgr, rgs, rgt, rgw = oracle64.march_backward(*a, ref_sat, g2, warp=warp, fadescale=fadescale, fadeexp=fadeexp)
     err = np.abs(rgba - ref_rgba).max(-1)
     assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "warp scene")
     # grad_warp is a scatter of dL/dy1 (a position gradient: white-noise slabs make it cancel heavily, like the pose
-    # gradients); held to cosine >= 0.9999, norm-wise 1e-2 and max-abs 1e-1 (see tests/test_gpu_fullsize.py for the
-    # calibration of these bounds with the float32 build of the oracle)
+    # gradients); held to cosine >= 0.9999, norm-wise 1e-2 and max-abs 1e-1 (2e-1 on the 8^3 grid, whose nodes collect
+    # fewer samples each).  Calibration: the float32 build of the ORACLE against its float64 build on these three
+    # scenes gives cosine 0.999994 / 0.999992 / 0.999978, norm-wise 3.5e-3 / 4.1e-3 / 6.6e-3 and max-abs
+    # 3.5e-2 / 1.4e-2 / 9.7e-2 -- the kernels sit in the same place (all three backward owners agree to 1e-6).
     gw = grads["warp"]
     stats = (cosine(gw, rgw), np.linalg.norm(gw - rgw) / np.linalg.norm(rgw), np.abs(gw - rgw).max() / np.abs(rgw).max())
-    assert stats[0] >= POSE_COS and stats[1] <= 1e-2 and stats[2] <= 1e-1, stats
+    assert stats[0] >= POSE_COS and stats[1] <= 1e-2 and stats[2] <= gw_maxabs, stats
 
 
 def test_heavy_scene_takes_the_exact_traversal_fallback(ops, oracle64):
