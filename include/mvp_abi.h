@@ -115,9 +115,9 @@ int mvp_march_forward_cams(int N, int H, int W, int K, const float *campos /*[N,
 /* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
  * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are OVERWRITTEN (every element is written; the
  * caller need not zero-fill them, unlike mvpraymarch.py:240-246).  With the forward's hand-off buffers the
- * primitive-centric kernel runs (no HBM atomics); primitives whose list overflowed primlist_cap, or everything
- * when the buffers are NULL / the slab exceeds the LDS budget / a warp field is used (algo 1; grad_warp is then
- * overwritten too), go through the ray-centric kernel with global_atomic_add_f32. */
+ * primitive-centric kernel runs (no HBM atomics; with a warp field -- algo 1 -- its warp-field variant, and grad_warp is
+ * overwritten too); primitives whose list overflowed primlist_cap, or everything when the buffers are NULL / the
+ * slab(s) exceed the LDS budget, go through the ray-centric kernel with global_atomic_add_f32. */
 int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                        const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,
                        const float *primscale, int TD, int TH, int TW, const float *tplate, int WD, int WH, int WW,
