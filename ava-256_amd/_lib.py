@@ -46,7 +46,11 @@ SIGNATURES["mvp_prim_placement_backward"] = (_c_int, [_c_int] * 9 + [_c_float] +
 SIGNATURES["mvp_grads_sanitize_sqnorm"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_void_p])
 # ntensors | grads, numels | sqnorm | max_norm | total_norm | stream
 SIGNATURES["mvp_grads_clip_scale"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_float] + [_c_void_p] * 2)
-ABI_VERSION = 8
+# B, HW | samplecoords, bias1, w1pos, wh, bh, w6, b6, acts, x0, out | stream
+SIGNATURES["mvp_bgmlp_forward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 10 + [_c_void_p])
+# B, HW | grad_out, acts, whT, w6, dz, colsum | stream
+SIGNATURES["mvp_bgmlp_backward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 6 + [_c_void_p])
+ABI_VERSION = 9
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -1,0 +1,85 @@
+"""Fused background MLP (second half): autograd binding of mvp_bgmlp_forward / mvp_bgmlp_backward.
+
+The per-pixel stack of /root/reference/models/bg/mlp2d.py:29-41 (1x1 convolutions 120 -> 256 x 5 -> 3, LeakyReLU(0.2))
+runs as one MFMA kernel per direction that keeps a 128-pixel tile's activations in LDS across all layers
+(csrc/bgmlp.hip).  The kernels produce the output and the chain of input gradients; weight and bias gradients are
+[256 x P] . [P x 256] GEMMs and column sums over the stored bf16 (activation, gradient) pairs, issued here."""
+import math
+
+import torch
+
+from . import _lib
+from ._tensors import ptr, stream_ptr
+
+WIDTH, POS, POS_PAD, HIDDEN, TILE = 256, 40, 48, 4, 128
+
+
+def positional_encoding(samplecoords: torch.Tensor) -> torch.Tensor:
+    """mlp2d.py:64-68: cat([sin(2^i pi x) for i < 10] + [cos(2^i pi x) for i < 10], -1) -> [..., 40]."""
+    return torch.cat([torch.sin(2 ** i * math.pi * samplecoords) for i in range(10)] +
+                     [torch.cos(2 ** i * math.pi * samplecoords) for i in range(10)], dim=-1)
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, chunks: int = 64) -> torch.Tensor:
+    """dy^T @ x for tall bf16 matrices [M, a], [M, b] with the M-reduction split into `chunks` batched GEMMs whose
+    partial products are summed in fp32 (a 256 x 256 output with K = M gives hipBLASLt 16 workgroups otherwise)."""
+    M = dy.shape[0]
+    S = chunks if M % chunks == 0 and M >= chunks * 256 else 1
+    return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).float().sum(0)
+
+
+class _FusedBgMlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, samplecoords, bias1, w1pos, w6, b6, *hidden):
+        # hidden = (W2, b2, W3, b3, W4, b4, W5, b5): weights [256,256] ([out][in]), biases [256]
+        if not samplecoords.is_cuda:
+            raise RuntimeError("fused background MLP: CUDA/HIP tensors only (no CPU fallback)")
+        B, H, W = samplecoords.shape[:3]
+        HW, dev = H * W, samplecoords.device
+        sc = samplecoords.detach().float().contiguous()
+        w1p = torch.zeros((WIDTH, POS_PAD), device=dev, dtype=torch.bfloat16)
+        w1p[:, :POS] = w1pos.detach()
+        whb = torch.stack([hidden[2 * i].detach() for i in range(HIDDEN)]).to(torch.bfloat16).contiguous()
+        bhf = torch.stack([hidden[2 * i + 1].detach() for i in range(HIDDEN)]).float().contiguous()
+        b1f, w6f, b6f = bias1.detach().float().contiguous(), w6.detach().float().contiguous(), b6.detach().float().contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        acts = torch.empty((HIDDEN + 1, B * HW, WIDTH), device=dev, dtype=torch.bfloat16) if need_grad else None
+        x0 = torch.empty((B * HW, POS_PAD), device=dev, dtype=torch.bfloat16) if need_grad else None
+        out = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().mvp_bgmlp_forward(B, HW, ptr(sc), ptr(b1f), ptr(w1p), ptr(whb), ptr(bhf), ptr(w6f),
+                                                        ptr(b6f), ptr(acts), ptr(x0), ptr(out), stream_ptr(dev)),
+                       "mvp_bgmlp_forward")
+        ctx.save_for_backward(x0, whb, w6f, acts)
+        ctx.dims = (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x0, whb, w6f, acts = ctx.saved_tensors
+        B, H, W = ctx.dims
+        HW, dev = H * W, x0.device
+        P, tiles = B * HW, (HW + TILE - 1) // TILE
+        gout = gout.float().contiguous()
+        whT = whb.transpose(1, 2).contiguous()
+        dz = torch.empty((HIDDEN + 1, P, WIDTH), device=dev, dtype=torch.bfloat16)
+        colsum = torch.empty((HIDDEN + 1, B, tiles, WIDTH), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().mvp_bgmlp_backward(B, HW, ptr(gout), ptr(acts), ptr(whT), ptr(w6f), ptr(dz),
+                                                         ptr(colsum), stream_ptr(dev)), "mvp_bgmlp_backward")
+        g_bias1 = colsum[0].sum(1)
+        g_w1pos = _wgrad(dz[0], x0)[:, :POS]
+        g6 = (gout.view(B, 3, HW).permute(0, 2, 1).reshape(P, 3) * 25.0)
+        g_w6 = _wgrad(g6.to(torch.bfloat16), acts[HIDDEN])
+        g_b6 = g6.sum(0)
+        hidden = []
+        for l in range(HIDDEN):
+            hidden += [_wgrad(dz[l + 1], acts[l]), colsum[l + 1].sum((0, 1))]
+        return (None, g_bias1, g_w1pos, g_w6, g_b6, *hidden)
+
+
+def fused_background_mlp(samplecoords, bias1, w1pos, hidden, w6, b6):
+    """samplecoords [B,H,W,2]; bias1 [B,256] (first-layer bias incl. the camera / identity codes); w1pos [256,40];
+    hidden = [(W, b)] x 4; w6 [3,256]; b6 [3]  ->  [B,3,H,W] = MLP * 25 + 100 (mlp2d.py:69-70)."""
+    flat = [t for wb in hidden for t in wb]
+    return _FusedBgMlp.apply(samplecoords, bias1, w1pos, w6, b6, *flat)

@@ -1,0 +1,355 @@
+// bgmlp.hip -- row N4 of SURVEY.md 8(f), second half: the per-pixel background MLP of the training loop
+// (/root/reference/models/bg/mlp2d.py:29-41,56-72) as two fused MFMA kernels.
+//
+// Reference: posenc = cat([sin(2^i pi x) for i < 10] + [cos(2^i pi x) for i < 10]) of the pixel's two normalised
+// coordinates (40 channels), concatenated with a 40-channel camera code and a 40-channel identity code that are
+// constant over an image, then 1x1 convolutions 120 -> 256 -> 256 -> 256 -> 256 -> 256 -> 3 with LeakyReLU(0.2)
+// between them, output * 25 + 100.  Per pixel 0.59 MFLOP; 154 GFLOP per 512 x 512 image: the largest dense
+// contraction of a training step, and the only genuine GEMM near the raymarch path.  In eager PyTorch (bf16
+// autocast) it is 6 GEMMs + ~25 elementwise / reduction kernels each way that move the [pixels, 256] activations
+// through HBM ~20 times; GEMM time is one third of the total (profiles/r02z_train_C3_kernel_stats.csv).
+//
+// Here: one workgroup (4 waves) owns a tile of 128 pixels and carries it through ALL layers.  The activations of the
+// tile stay in LDS as bf16 ([128][256 + 8]: the 16-byte pad makes the MFMA A-fragment reads conflict-free); each
+// wave computes a 64 x 128 block of the tile's [128 x 256] output with v_mfma_f32_32x32x16_bf16 (8 accumulator tiles
+// = 128 registers), reading its B fragments -- 8 consecutive input channels of one output channel, i.e. 16 contiguous
+// bytes of the nn.Linear weight layout [out][in] -- straight from global memory (128 KB per layer, L2-resident and
+// shared by every workgroup).  Bias + LeakyReLU are applied on the accumulators, the result goes back to LDS as the
+// next layer's input and (training) to HBM once, as bf16, for the backward.  The camera / identity codes enter as a
+// per-image bias of the first layer (their 80 input channels are constant over the image), so the first GEMM has
+// K = 40 (padded to 48).  The last layer (256 -> 3) is a VALU dot product.
+//
+// Backward: the same tile walk in reverse for the INPUT gradients (dZ_l = (dZ_{l+1} . W_{l+1}) * leaky'(A_l)), with
+// the transposed weights as B operand; dZ_l is written once as bf16.  Weight and bias gradients are plain
+// [256 x P] . [P x 256] GEMMs / column sums over the stored (A_{l-1}, dZ_l) pairs and stay with the BLAS library
+// (ava-256_amd/bgmlp.py).
+//
+// MFMA operand maps (verified on the device: tools/ubench/mfma_probe.hip): A: lane l holds A[l % 32][8 (l / 32) + 0..7];
+// B: lane l holds B[8 (l / 32) + 0..7][l % 32]; D: register r of lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+#include "mvp_device.h"
+#include "mvp_host.h"
+
+namespace mvp {
+namespace bgmlp {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kTileM = 128;          // pixels per workgroup tile
+constexpr int kWidth = 256;          // hidden width
+constexpr int kLdX = kWidth + 8;     // LDS row stride (bf16 elements): 528 bytes
+constexpr int kPos = 40;             // positional channels
+constexpr int kK0 = 48;              // ... padded to three MFMA k-steps
+constexpr int kHidden = 4;           // 256 -> 256 layers
+constexpr int kThreads = 256;
+constexpr float kSlope = 0.2f;       // LeakyReLU(0.2), mlp2d.py:30-38
+
+struct Params {
+    int B, HW, tiles_per_image;
+    const float *samplecoords;  // [B, HW, 2]
+    const float *bias1;         // [B, 256]: b1 + W1[:, :80] . (camera code, identity code)
+    const __bf16 *w1pos;        // [256][48]: W1[:, 80:120], zero padded
+    const __bf16 *wh;           // forward: [4][256][256] = W_l [out][in]; backward: W_l^T [in][out]
+    const float *bh;            // [4][256]
+    const float *w6;            // [3][256]
+    const float *b6;            // [3]
+    __bf16 *acts;               // [5][B*HW][256] post-activation outputs of the five hidden layers (NULL: not kept)
+    float *out;                 // [B, 3, HW]
+    const float *grad_out;      // [B, 3, HW]
+    __bf16 *dz;                 // [5][B*HW][256] gradients w.r.t. the five pre-activations
+    __bf16 *x0;                 // [B*HW][48] positional encoding as the first GEMM consumed it (kept for its weight gradient)
+    float *colsum;              // [5][B*tiles_per_image][256] per-tile column sums of dz (bias gradients, summed by the caller)
+};
+
+// acc[mi][ni] (+)= X[64 mh + 32 mi .., :K] . W[128 nh + 32 ni .., :K]^T   (X in LDS, W in global memory, row stride K)
+template <int K>
+__device__ __forceinline__ void tile_gemm(const __bf16 *X, const __bf16 *__restrict__ W, f32x16 (&acc)[2][4], int mh,
+                                          int nh, int lane) {
+    const int lr = lane & 31, lk = (lane >> 5) * 8;
+    const __bf16 *xa = X + (64 * mh + lr) * kLdX + lk;
+    const __bf16 *wb = W + (size_t)(128 * nh + lr) * K + lk;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        bf16x8 a[2], b[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8 *>(wb + (size_t)ni * 32 * K + k0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8 *>(xa + mi * 32 * kLdX + k0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// accumulators -> LDS tile as bf16; ACT: + bias[col], LeakyReLU
+template <bool ACT>
+__device__ __forceinline__ void acc_to_lds(__bf16 *X, const f32x16 (&acc)[2][4], const float *__restrict__ bias, int mh,
+                                           int nh, int lane) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int col = 128 * nh + 32 * ni + (lane & 31);
+        const float bb = ACT ? bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 64 * mh + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[mi][ni][r] + bb;
+                if (ACT) v = v > 0.f ? v : kSlope * v;
+                X[row * kLdX + col] = (__bf16)v;
+            }
+        }
+    }
+}
+
+// LDS tile -> global [rows][256] bf16, 16 bytes per thread and pass (rows >= nvalid are not written)
+__device__ __forceinline__ void lds_to_global(const __bf16 *X, __bf16 *__restrict__ G, int nvalid, int tid) {
+#pragma unroll 4
+    for (int i = tid; i < kTileM * (kWidth / 8); i += kThreads) {
+        const int row = i >> 5, c8 = (i & 31) * 8;
+        if (row < nvalid)
+            *reinterpret_cast<bf16x8 *>(G + (size_t)row * kWidth + c8) = *reinterpret_cast<const bf16x8 *>(X + row * kLdX + c8);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *X = reinterpret_cast<__bf16 *>(smem);
+    float *red = reinterpret_cast<float *>(smem + kTileM * kLdX * 2);  // [256][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mh = wave & 1, nh = wave >> 1;
+    const int b = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - b * p.tiles_per_image) * kTileM;
+    const int nvalid = min(kTileM, p.HW - p0);
+    const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
+
+    // ---- positional encoding of the tile (mlp2d.py:64-68): channel 2 i + j = sin(2^i pi x_j), 20 + 2 i + j = cos ----
+    {
+        const int r = tid & 127, half = tid >> 7;  // half 0: sines, half 1: cosines + the zero padding
+        float x0 = 0.f, x1 = 0.f;
+        if (r < nvalid) {
+            const float2 sc = reinterpret_cast<const float2 *>(p.samplecoords)[pix0 + r];
+            x0 = sc.x, x1 = sc.y;
+        }
+        __bf16 *row = X + r * kLdX + half * 20;
+        float f = 1.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            row[2 * i] = (__bf16)(half ? cospif(f * x0) : sinpif(f * x0));
+            row[2 * i + 1] = (__bf16)(half ? cospif(f * x1) : sinpif(f * x1));
+            f *= 2.f;
+        }
+        if (half) {
+#pragma unroll
+            for (int c = kPos; c < kK0; ++c) X[r * kLdX + c] = (__bf16)0.f;
+        }
+    }
+    __syncthreads();
+    if (p.x0) {  // 96 bytes per pixel, 16 bytes per thread and pass
+        for (int i = tid; i < kTileM * (kK0 / 8); i += kThreads) {
+            const int row = i / (kK0 / 8), c8 = (i - row * (kK0 / 8)) * 8;
+            if (row < nvalid)
+                *reinterpret_cast<bf16x8 *>(p.x0 + (pix0 + row) * kK0 + c8) = *reinterpret_cast<const bf16x8 *>(X + row * kLdX + c8);
+        }
+    }
+    f32x16 acc[2][4];
+    // ---- layer 1: 40 (48) -> 256, per-image bias ----
+    tile_gemm<kK0>(X, p.w1pos, acc, mh, nh, lane);
+    __syncthreads();
+    acc_to_lds<true>(X, acc, p.bias1 + (size_t)b * kWidth, mh, nh, lane);
+    __syncthreads();
+    if (p.acts) lds_to_global(X, p.acts + pix0 * kWidth, nvalid, tid);
+    // ---- layers 2..5: 256 -> 256 ----
+    for (int l = 0; l < kHidden; ++l) {
+        tile_gemm<kWidth>(X, p.wh + (size_t)l * kWidth * kWidth, acc, mh, nh, lane);
+        __syncthreads();  // every wave has read the whole tile
+        acc_to_lds<true>(X, acc, p.bh + l * kWidth, mh, nh, lane);
+        __syncthreads();
+        if (p.acts) lds_to_global(X, p.acts + ((size_t)(l + 1) * P + pix0) * kWidth, nvalid, tid);
+    }
+    // ---- layer 6: 256 -> 3, * 25 + 100 (mlp2d.py:40,70) ----
+    {
+        const int r = tid & 127, half = tid >> 7;
+        const __bf16 *xr = X + r * kLdX + half * 128;
+        const float *w = p.w6 + half * 128;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < 128; k += 8) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(xr + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xf = (float)xv[e];
+                s0 = fmaf(xf, w[k + e], s0), s1 = fmaf(xf, w[kWidth + k + e], s1), s2 = fmaf(xf, w[2 * kWidth + k + e], s2);
+            }
+        }
+        red[tid * 3 + 0] = s0, red[tid * 3 + 1] = s1, red[tid * 3 + 2] = s2;
+    }
+    __syncthreads();
+    if (tid < 128 && tid < nvalid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = red[tid * 3 + c] + red[(tid + 128) * 3 + c] + p.b6[c];
+            p.out[((size_t)b * 3 + c) * p.HW + p0 + tid] = v * 25.f + 100.f;
+        }
+    }
+}
+
+// dst tile (LDS, bf16) *= leaky'(A) with A from global; result also to global dz
+// `cs` accumulates this thread's 8 columns (c8 = 8 (tid & 31) .. + 7) over its 16 rows: the bias gradient's partial sum
+__device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *__restrict__ A, __bf16 *__restrict__ DZ, int nvalid,
+                                               int tid, float (&cs)[8]) {
+#pragma unroll 2
+    for (int i = tid; i < kTileM * (kWidth / 8); i += kThreads) {
+        const int row = i >> 5, c8 = (i & 31) * 8;
+        bf16x8 g = *reinterpret_cast<const bf16x8 *>(X + row * kLdX + c8);
+        if (row < nvalid) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(A + (size_t)row * kWidth + c8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                g[e] = (__bf16)((float)g[e] * ((float)a[e] > 0.f ? 1.f : kSlope));
+                cs[e] += (float)g[e];
+            }
+            *reinterpret_cast<bf16x8 *>(DZ + (size_t)row * kWidth + c8) = g;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8 *>(X + row * kLdX + c8) = g;
+    }
+}
+
+// column sums of the tile: 8 threads (tid >> 5) hold partial sums of the same 8 columns -> LDS -> one row of `out`
+__device__ __forceinline__ void reduce_colsum(float *scratch /*[8][256]*/, const float (&cs)[8], float *__restrict__ out, int tid) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) scratch[(tid >> 5) * kWidth + (tid & 31) * 8 + e] = cs[e];
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += scratch[j * kWidth + tid];
+    out[tid] = s;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads, 2) void bwd_kernel(const Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16 *X = reinterpret_cast<__bf16 *>(smem);
+    float *gl = reinterpret_cast<float *>(smem + kTileM * kLdX * 2);  // [128][3] upstream gradient * 25
+    float *scratch = gl + kTileM * 3;                                  // [8][256] column-sum staging
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mh = wave & 1, nh = wave >> 1;
+    const int b = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - b * p.tiles_per_image) * kTileM;
+    const int nvalid = min(kTileM, p.HW - p0);
+    const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
+
+    if (tid < 128) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            gl[tid * 3 + c] = tid < nvalid ? 25.f * p.grad_out[((size_t)b * 3 + c) * p.HW + p0 + tid] : 0.f;
+    }
+    __syncthreads();
+    const size_t ntiles = (size_t)p.B * p.tiles_per_image;
+    float cs[8];
+    // ---- dA5 = g . W6 (K = 3: VALU), dZ5 = dA5 * leaky'(A5) ----
+    {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+        const __bf16 *A = p.acts + (4 * P + pix0) * kWidth;
+        __bf16 *DZ = p.dz + (4 * P + pix0) * kWidth;
+        for (int i = tid; i < kTileM * (kWidth / 8); i += kThreads) {
+            const int row = i >> 5, c8 = (i & 31) * 8;
+            const float g0 = gl[row * 3], g1 = gl[row * 3 + 1], g2 = gl[row * 3 + 2];
+            bf16x8 g;
+            if (row < nvalid) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(A + (size_t)row * kWidth + c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float da = g0 * p.w6[c8 + e] + g1 * p.w6[kWidth + c8 + e] + g2 * p.w6[2 * kWidth + c8 + e];
+                    g[e] = (__bf16)(da * ((float)a[e] > 0.f ? 1.f : kSlope));
+                    cs[e] += (float)g[e];
+                }
+                *reinterpret_cast<bf16x8 *>(DZ + (size_t)row * kWidth + c8) = g;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8 *>(X + row * kLdX + c8) = g;
+        }
+    }
+    __syncthreads();
+    reduce_colsum(scratch, cs, p.colsum + (4 * ntiles + blockIdx.x) * kWidth, tid);
+    // ---- dZ_l = (dZ_{l+1} . W_{l+1}) * leaky'(A_l), l = 4..1 ----
+    f32x16 acc[2][4];
+    for (int l = kHidden - 1; l >= 0; --l) {
+        tile_gemm<kWidth>(X, p.wh + (size_t)l * kWidth * kWidth, acc, mh, nh, lane);  // p.wh = transposed weights here
+        __syncthreads();
+        acc_to_lds<false>(X, acc, nullptr, mh, nh, lane);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+        mask_and_store(X, p.acts + ((size_t)l * P + pix0) * kWidth, p.dz + ((size_t)l * P + pix0) * kWidth, nvalid, tid, cs);
+        __syncthreads();
+        reduce_colsum(scratch, cs, p.colsum + ((size_t)l * ntiles + blockIdx.x) * kWidth, tid);
+    }
+}
+
+}  // namespace bgmlp
+}  // namespace mvp
+
+static int bgmlp_common(int B, int HW, mvp::bgmlp::Params &p) {
+    if (B < 0 || HW < 0) return MVP_ERR_BADARG;
+    if ((long long)B * HW == 0) return 1;
+    p.B = B, p.HW = HW;
+    p.tiles_per_image = (HW + mvp::bgmlp::kTileM - 1) / mvp::bgmlp::kTileM;
+    if ((long long)B * p.tiles_per_image > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
+    return MVP_OK;
+}
+
+extern "C" int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const float *bias1, const void *w1pos,
+                                 const void *wh, const float *bh, const float *w6, const float *b6, void *acts,
+                                 void *x0, float *out, void *stream) {
+    using namespace mvp;
+    using namespace mvp::bgmlp;
+    Params p = {};
+    int rc = bgmlp_common(B, HW, p);
+    if (rc == 1) return MVP_OK;
+    if (rc != MVP_OK) return rc;
+    if (!samplecoords || !bias1 || !w1pos || !wh || !bh || !w6 || !b6 || !out) return MVP_ERR_BADARG;
+    if (!aligned16(w1pos) || !aligned16(wh) || (acts && !aligned16(acts)) || (x0 && !aligned16(x0)) ||
+        ((uintptr_t)samplecoords & 7u))
+        return MVP_ERR_BADARG;
+    p.samplecoords = samplecoords, p.bias1 = bias1, p.w1pos = static_cast<const __bf16 *>(w1pos);
+    p.wh = static_cast<const __bf16 *>(wh), p.bh = bh, p.w6 = w6, p.b6 = b6;
+    p.acts = static_cast<__bf16 *>(acts), p.x0 = static_cast<__bf16 *>(x0), p.out = out;
+    const size_t lds = (size_t)kTileM * kLdX * 2 + kThreads * 3 * sizeof(float);
+    // 69 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU; two workgroups fit)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+extern "C" int mvp_bgmlp_backward(int B, int HW, const float *grad_out, const void *acts, const void *whT, const float *w6,
+                                  void *dz, float *colsum, void *stream) {
+    using namespace mvp;
+    using namespace mvp::bgmlp;
+    Params p = {};
+    int rc = bgmlp_common(B, HW, p);
+    if (rc == 1) return MVP_OK;
+    if (rc != MVP_OK) return rc;
+    if (!grad_out || !acts || !whT || !w6 || !dz || !colsum) return MVP_ERR_BADARG;
+    if (!aligned16(acts) || !aligned16(whT) || !aligned16(dz)) return MVP_ERR_BADARG;
+    p.grad_out = grad_out, p.acts = const_cast<__bf16 *>(static_cast<const __bf16 *>(acts));
+    p.wh = static_cast<const __bf16 *>(whT), p.w6 = w6, p.dz = static_cast<__bf16 *>(dz), p.colsum = colsum;
+    const size_t lds = (size_t)kTileM * kLdX * 2 + (kTileM * 3 + 8 * kWidth) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
+    return launch_status();
+}

@@ -134,9 +134,11 @@ class BackgroundMLPStandIn(nn.Module):
     154 GFLOP per 512 x 512 image forward, the largest dense contraction of the training step.
     `autocast_dtype` (bf16 by default) is applied on CUDA only: the 1x1 convolutions run as MFMA GEMMs."""
 
-    def __init__(self, ncams: int, nident: int, width: int = 256, autocast_dtype=torch.bfloat16, seed: int = 0):
+    def __init__(self, ncams: int, nident: int, width: int = 256, autocast_dtype=torch.bfloat16, seed: int = 0,
+                 fused: bool = True):
         super().__init__()
         self.ncams, self.nident, self.autocast_dtype = ncams, nident, autocast_dtype
+        self.fused = fused and width == 256   # CUDA + bf16: the fused MFMA kernels instead of eager autocast GEMMs
         act = lambda: nn.LeakyReLU(0.2)
         self.cammod = nn.Sequential(nn.Linear(ncams, 256), act(), nn.Linear(256, 40))
         self.idmod = nn.Sequential(nn.Linear(nident, 256), act(), nn.Linear(256, 40))
@@ -159,13 +161,22 @@ class BackgroundMLPStandIn(nn.Module):
     def forward(self, camindex, idindex, samplecoords):
         b, h, w = samplecoords.shape[0], samplecoords.shape[1], samplecoords.shape[2]
         dev = samplecoords.device
+        if dev.type == "cuda" and self.fused and self.autocast_dtype is torch.bfloat16:
+            # one MFMA kernel per direction (csrc/bgmlp.hip).  The two codes are constant over an image: their 80 input
+            # channels of the first layer become a per-image bias (fp32, differentiable through plain autograd).
+            from .bgmlp import fused_background_mlp
+            camenc = self.cammod(torch.nn.functional.one_hot(camindex, self.ncams).float())
+            idenc = self.idmod(torch.nn.functional.one_hot(idindex, self.nident).float())
+            lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+            bias1 = lin[0].bias + torch.cat([camenc, idenc], dim=-1) @ lin[0].weight[:, :80].t()
+            return fused_background_mlp(samplecoords, bias1, lin[0].weight[:, 80:], [(m.weight, m.bias) for m in lin[1:5]],
+                                        lin[5].weight, lin[5].bias)
         use_amp = dev.type == "cuda" and self.autocast_dtype is not None
         with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype or torch.bfloat16, enabled=use_amp):
             camenc = self.cammod(torch.nn.functional.one_hot(camindex, self.ncams).float())
             idenc = self.idmod(torch.nn.functional.one_hot(idindex, self.nident).float())
-            freqs = (2.0 ** torch.arange(10, device=dev, dtype=torch.float32)) * math.pi
-            ang = samplecoords[..., None] * freqs                                   # [b,h,w,2,10]
-            posenc = torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1).reshape(b, h, w, 40)
+            posenc = torch.cat([torch.sin(2 ** i * math.pi * samplecoords) for i in range(10)] +
+                               [torch.cos(2 ** i * math.pi * samplecoords) for i in range(10)], dim=-1)   # mlp2d.py:64-68
             x = torch.cat([camenc[:, None, None, :].expand(b, h, w, 40).to(posenc.dtype),
                            idenc[:, None, None, :].expand(b, h, w, 40).to(posenc.dtype), posenc], dim=-1)
             out = self.mlp(x)                                                       # [b,h,w,3]

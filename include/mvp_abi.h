@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 8
+#define MVP_ABI_VERSION 9
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -179,6 +179,30 @@ int mvp_grads_sanitize_sqnorm(int ntensors, float *const *grads, const long long
                               void *stream);
 int mvp_grads_clip_scale(int ntensors, float *const *grads, const long long *numels, const double *sqnorm,
                          float max_norm, float *total_norm /*or NULL*/, void *stream);
+
+/* Per-pixel background MLP of the training loop (second half) as two fused MFMA kernels.  No
+ * native counterpart in the reference: there it is `BackgroundModelSimple.mlp`, six 1x1 Conv2d with LeakyReLU(0.2)
+ * (/root/reference/models/bg/mlp2d.py:29-41), applied to cat(camera code, identity code, positional encoding) at
+ * :61-70, output * 25 + 100.  The two 40-channel codes are constant over an image: they enter as a per-image bias.
+ *   samplecoords [B,HW,2] float32 (normalised pixel coordinates; the 20 sin + 20 cos channels are made in the kernel,
+ *                channel order of mlp2d.py:64-68)
+ *   bias1  [B,256] float32 = b1 + W1[:, 0:80] . cat(camera code, identity code)
+ *   w1pos  [256,48] bf16   = W1[:, 80:120] zero-padded to 48 input channels
+ *   wh     [4,256,256] bf16 = weights of the four 256 -> 256 layers, nn.Linear / Conv2d layout [out][in]
+ *   bh     [4,256] float32, w6 [3,256] float32, b6 [3] float32
+ *   acts   [5, B*HW, 256] bf16, written when not NULL: the post-activation outputs of the five hidden layers
+ *   x0     [B*HW, 48] bf16, written when not NULL: the positional encoding as the first GEMM consumed it
+ *   out    [B,3,HW] float32 (NCHW planes)
+ * bf16 operands, fp32 accumulation.  Backward: dz [5, B*HW, 256] bf16 = gradients w.r.t. the five pre-activations
+ * (the chain of input gradients), from grad_out [B,3,HW] and `acts`; whT holds the transposed hidden weights
+ * [4,256,256] = [in][out]; colsum [5, B*ceil(HW/128), 256] float32 = column sums of dz per 128-pixel tile (tiles of one
+ * image are consecutive: summed over an image they are the gradient of bias1, over everything of bh).  Weight gradients
+ * are [256 x P] . [P x 256] GEMMs over (x0 | acts, dz), left to the caller's BLAS. */
+int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const float *bias1, const void *w1pos, const void *wh,
+                      const float *bh, const float *w6, const float *b6, void *acts /*or NULL*/, void *x0 /*or NULL*/,
+                      float *out, void *stream);
+int mvp_bgmlp_backward(int B, int HW, const float *grad_out, const void *acts, const void *whT, const float *w6,
+                       void *dz, float *colsum, void *stream);
 
 #ifdef __cplusplus
 }

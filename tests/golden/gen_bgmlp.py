@@ -1,0 +1,43 @@
+"""Golden vectors for the background MLP: the reference's own BackgroundModelSimple
+(/root/reference/models/bg/mlp2d.py:14-72) run here on CPU in float32 with seeded weights.
+Output: tests/golden/bgmlp.npz = inputs, every parameter, the output and the gradients of a fixed linear loss.
+Run in the build container only (needs /root/reference):  python tests/golden/gen_bgmlp.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+from models.bg.mlp2d import BackgroundModelSimple  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    torch.manual_seed(77)
+    ncams, nident, B, H, W = 3, 2, 2, 12, 20
+    m = BackgroundModelSimple(ncams, nident)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():  # initseq leaves small weights and zero biases: make every term of the forward matter
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    camindex = torch.tensor([2, 0])
+    idindex = torch.tensor([1, 1])
+    samplecoords = torch.rand(B, H, W, 2, generator=g) * 2 - 1
+    gout = torch.randn(B, 3, H, W, generator=g)
+    bg = m(camindex, idindex, samplecoords)
+    (bg * gout).sum().backward()
+    out = dict(camindex=camindex.numpy(), idindex=idindex.numpy(), samplecoords=samplecoords.numpy(), gout=gout.numpy(),
+               bg=bg.detach().numpy())
+    for k, v in m.state_dict().items():
+        out["param/" + k] = v.numpy()
+    for k, p in m.named_parameters():
+        out["grad/" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "bgmlp.npz"), **out)
+    print("bgmlp.npz:", {k: v.shape for k, v in out.items() if not k.startswith("param/mlp")})
+
+
+if __name__ == "__main__":
+    main()
