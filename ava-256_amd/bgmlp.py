@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._tensors import ptr, stream_ptr
 
-WIDTH, POS, POS_PAD, HIDDEN, TILE = 256, 40, 48, 4, 128
+WIDTH, POS, POS_PAD, HIDDEN, TILE = 256, 40, 48, 4, 256
 
 
 def positional_encoding(samplecoords: torch.Tensor) -> torch.Tensor:

@@ -9,13 +9,16 @@
 // autocast) it is 6 GEMMs + ~25 elementwise / reduction kernels each way that move the [pixels, 256] activations
 // through HBM ~20 times; GEMM time is one third of the total (profiles/r02z_train_C3_kernel_stats.csv).
 //
-// Here: one workgroup (4 waves) owns a tile of 128 pixels and carries it through ALL layers.  The activations of the
-// tile stay in LDS as bf16 ([128][256 + 8]: the 16-byte pad makes the MFMA A-fragment reads conflict-free); each
-// wave computes a 64 x 128 block of the tile's [128 x 256] output with v_mfma_f32_32x32x16_bf16 (8 accumulator tiles
-// = 128 registers), reading its B fragments -- 8 consecutive input channels of one output channel, i.e. 16 contiguous
-// bytes of the nn.Linear weight layout [out][in] -- straight from global memory (128 KB per layer, L2-resident and
-// shared by every workgroup).  Bias + LeakyReLU are applied on the accumulators, the result goes back to LDS as the
-// next layer's input and (training) to HBM once, as bf16, for the backward.  The camera / identity codes enter as a
+// Here: one workgroup (8 waves, one per CU) owns a tile of 256 pixels and carries it through ALL layers.  The
+// activations of the tile stay in LDS as bf16 ([256][256 + 8], 132 KB: the 16-byte pad makes the MFMA A-fragment reads
+// conflict-free); each wave computes a 64 x 128 block of the tile's [256 x 256] output with v_mfma_f32_32x32x16_bf16
+// (8 accumulator tiles = 128 registers).  The weights (128 KB per layer, L2-resident, nn.Linear layout [out][in]: the 8
+// consecutive input channels a B fragment needs are 16 contiguous bytes) stream through a 2 x 8 KB LDS ring in chunks of
+// 16 input channels: every thread fetches 16 bytes of chunk c + 4 into a register while chunk c is multiplied, so an
+// L2 round trip is covered by three chunks of MFMA work, and a weight element is read once per 256 pixels.  (A first
+// version with 128-pixel tiles whose waves read their B fragments straight from global memory ran at 370 TFLOP/s:
+// each k-step waited for an L2 round trip.)  Bias + LeakyReLU are applied on the accumulators, the result goes back to
+// LDS as the next layer's input and (training) to HBM once, as bf16, for the backward.  The camera / identity codes enter as a
 // per-image bias of the first layer (their 80 input channels are constant over the image), so the first GEMM has
 // K = 40 (padded to 48).  The last layer (256 -> 3) is a VALU dot product.
 //
@@ -29,19 +32,27 @@
 #include "mvp_device.h"
 #include "mvp_host.h"
 
+#ifndef BG_EXP
+#define BG_EXP 0  // timing experiments (wrong results by construction): 1 no epilogue, 2 no MFMA, 3 no k-loop barriers, 4 no LDS fragment reads
+#endif
+
 namespace mvp {
 namespace bgmlp {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kTileM = 128;          // pixels per workgroup tile
+constexpr int kTileM = 256;          // pixels per workgroup tile
 constexpr int kWidth = 256;          // hidden width
 constexpr int kLdX = kWidth + 8;     // LDS row stride (bf16 elements): 528 bytes
 constexpr int kPos = 40;             // positional channels
 constexpr int kK0 = 48;              // ... padded to three MFMA k-steps
 constexpr int kHidden = 4;           // 256 -> 256 layers
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;        // 8 waves: 4 (rows) x 2 (columns) blocks of 64 x 128
+constexpr int kChunk = 16;           // input channels per weight chunk = one MFMA k-step
+constexpr int kRingElems = kWidth * kChunk;  // bf16 elements per ring buffer (8 KB)
+constexpr int kRing = 3;             // ring buffers: one being multiplied, one being read into fragments, one being written
 constexpr float kSlope = 0.2f;       // LeakyReLU(0.2), mlp2d.py:30-38
 
 struct Params {
@@ -61,50 +72,139 @@ struct Params {
     float *colsum;              // [5][B*tiles_per_image][256] per-tile column sums of dz (bias gradients, summed by the caller)
 };
 
-// acc[mi][ni] (+)= X[64 mh + 32 mi .., :K] . W[128 nh + 32 ni .., :K]^T   (X in LDS, W in global memory, row stride K)
-template <int K>
-__device__ __forceinline__ void tile_gemm(const __bf16 *X, const __bf16 *__restrict__ W, f32x16 (&acc)[2][4], int mh,
-                                          int nh, int lane) {
+// The weights of all layers form ONE stream of 16-channel chunks (forward: 3 chunks of W1's positional part, then 4 x 16
+// of the hidden layers; backward: 4 x 16 of the transposed hidden layers, last layer first).  Chunk g of the stream is
+// 8 KB: element (n, k) at n * 16 + k, thread t stages the 16 bytes (n = t >> 1, k = 8 (t & 1) ..).  `g` is a
+// compile-time constant wherever this is called (fully unrolled loops), so the layer arithmetic folds away.
+template <bool FWD>
+__device__ __forceinline__ const __bf16 *chunk_ptr(const Params &p, int g, int tid) {
+    if (FWD && g < kK0 / kChunk) return p.w1pos + (tid >> 1) * kK0 + (tid & 1) * 8 + g * kChunk;
+    const int h = FWD ? g - kK0 / kChunk : g;
+    const int l = FWD ? (h >> 4) : kHidden - 1 - (h >> 4), c = h & 15;
+    return p.wh + (size_t)l * kWidth * kWidth + (tid >> 1) * kWidth + (tid & 1) * 8 + c * kChunk;
+}
+constexpr int kFwdChunks = kK0 / kChunk + kHidden * (kWidth / kChunk);  // 67
+constexpr int kBwdChunks = kHidden * (kWidth / kChunk);                 // 64
+constexpr int kQueue = 4;  // chunks in flight per thread (registers), i.e. an L2 round trip is covered by ~4 k-steps of MFMA
+
+// acc[mi][ni] = (X[64 mq + 32 mi .., :K] . W[128 nh + 32 ni .., :K]^T)^T for the layer whose weights are chunks
+// G0 .. G0 + K/16 - 1 of the stream.  The MFMA is issued with the WEIGHT fragment as A and the activation fragment as B,
+// so a lane ends up with 4 consecutive output channels of one pixel per register quad (8-byte LDS writes in the
+// epilogue instead of 2-byte ones).
+// Software pipeline, one barrier per k-step: during step c a thread (1) writes its 16 bytes of chunk c + 2 from the
+// register queue into ring buffer (c + 2) % 3 and re-fills that queue slot with chunk c + 6 from global memory, (2)
+// issues the LDS reads of the fragments of step c + 1, (3) issues the 8 MFMAs of step c on fragments read one step
+// earlier -- so neither the L2 round trip nor the LDS read latency sits between two MFMA groups.  The barrier that opens
+// step c makes chunk c + 1 (written during step c - 1) visible; the buffer overwritten in step c held chunk c - 1, whose
+// fragments every wave received before it issued its MFMAs of step c - 1, i.e. before that barrier.
+// q[] is the register queue: on entry q[(G0 + j) % 4] holds chunk G0 + j (j < 4), on exit the same for the next layer
+// (the prefetch runs across layer boundaries).  The caller guarantees the ring is idle on entry (a barrier since its
+// last use, incl. its use as scratch).
+template <int K, int G0, bool FWD>
+__device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Params &p, bf16x8 (&q)[kQueue],
+                                          f32x16 (&acc)[2][4], int mq, int nh, int lane, int tid) {
+    constexpr int NC = K / kChunk, GT = FWD ? kFwdChunks : kBwdChunks;
     const int lr = lane & 31, lk = (lane >> 5) * 8;
-    const __bf16 *xa = X + (64 * mh + lr) * kLdX + lk;
-    const __bf16 *wb = W + (size_t)(128 * nh + lr) * K + lk;
+    const __bf16 *xa = X + (64 * mq + lr) * kLdX + lk;
+    __bf16 *dst = Wr + tid * 8;
+    const __bf16 *wb = Wr + (128 * nh + lr) * kChunk + lk;
+#define MVP_STAGE(G_)                                                                                         \
+    {                                                                                                         \
+        *reinterpret_cast<bf16x8 *>(dst + ((G_) % kRing) * kRingElems) = q[(G_) % kQueue];                    \
+        if ((G_) + kQueue < GT)                                                                               \
+            q[(G_) % kQueue] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<FWD>(p, (G_) + kQueue, tid));      \
+    }
+#define MVP_FRAGS(A_, B_, C_)                                                                                 \
+    {                                                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) B_[ni] =                                             \
+            *reinterpret_cast<const bf16x8 *>(wb + ((G0 + (C_)) % kRing) * kRingElems + ni * 32 * kChunk);    \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) A_[mi] =                                             \
+            *reinterpret_cast<const bf16x8 *>(xa + mi * 32 * kLdX + (C_) * kChunk);                           \
+    }
+    MVP_STAGE(G0)
+    if (NC > 1) MVP_STAGE(G0 + 1)
+    __syncthreads();
+    bf16x8 a[2][2], b[2][4];  // [parity of the step][..]
+    MVP_FRAGS(a[0], b[0], 0)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-#pragma unroll
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        bf16x8 a[2], b[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const bf16x8 *>(wb + (size_t)ni * 32 * K + k0);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const bf16x8 *>(xa + mi * 32 * kLdX + k0);
+    for (int c = 0; c < NC; ++c) {
+#if BG_EXP != 3
+        if (c > 0) __syncthreads();
+#endif
+        if (c + 2 < NC) MVP_STAGE(G0 + c + 2)
+#if BG_EXP != 4
+        if (c + 1 < NC) MVP_FRAGS(a[(c + 1) & 1], b[(c + 1) & 1], c + 1)
+#else
+        a[(c + 1) & 1][0] = a[c & 1][1], a[(c + 1) & 1][1] = a[c & 1][0];
+        b[(c + 1) & 1][0] = b[c & 1][1], b[(c + 1) & 1][1] = b[c & 1][2], b[(c + 1) & 1][2] = b[c & 1][3], b[(c + 1) & 1][3] = b[c & 1][0];
+#endif
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 4; ++ni) {
+#if BG_EXP == 2
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                }
+                acc[mi][ni][c & 15] += (float)b[c & 1][ni][mi] * (float)a[c & 1][mi][ni];
+#else
+                if (c == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][ni], a[0][mi], zero, 0, 0, 0);
+                } else {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c & 1][ni], a[c & 1][mi], acc[mi][ni], 0, 0, 0);
+                }
+#endif
+            }
     }
+#undef MVP_STAGE
+#undef MVP_FRAGS
 }
 
-// accumulators -> LDS tile as bf16; ACT: + bias[col], LeakyReLU
+// accumulators -> LDS tile as bf16; ACT: + bias[channel], LeakyReLU.  Register 4 u + e of tile (mi, ni) is channel
+// 128 nh + 32 ni + 8 u + 4 (lane >> 5) + e of pixel 64 mq + 32 mi + (lane & 31): four consecutive channels per store.
 template <bool ACT>
-__device__ __forceinline__ void acc_to_lds(__bf16 *X, const f32x16 (&acc)[2][4], const float *__restrict__ bias, int mh,
+__device__ __forceinline__ void acc_to_lds(__bf16 *X, const f32x16 (&acc)[2][4], const float *__restrict__ bias, int mq,
                                            int nh, int lane) {
+#if BG_EXP == 1
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
+        if (t == 123.456f) X[lane] = (__bf16)t;
+        return;
+    }
+#endif
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-        const int col = 128 * nh + 32 * ni + (lane & 31);
-        const float bb = ACT ? bias[col] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int u = 0; u < 4; ++u) {
+            const int n0 = 128 * nh + 32 * ni + 8 * u + 4 * (lane >> 5);
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ACT) {
+                bb = *reinterpret_cast<const float4 *>(bias + n0);
+                asm volatile("" ::: "memory");  // keep the 16 bias loads of a layer from being hoisted (and spilled) together
+            }
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 64 * mh + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[mi][ni][r] + bb;
-                if (ACT) v = v > 0.f ? v : kSlope * v;
-                X[row * kLdX + col] = (__bf16)v;
+            for (int mi = 0; mi < 2; ++mi) {
+                const int pix = 64 * mq + 32 * mi + (lane & 31);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[mi][ni][4 * u + e];
+                    if (ACT) {
+                        v += bv[e];
+                        v = fmaxf(v, kSlope * v);  // LeakyReLU(0.2): max(v, 0.2 v)
+                    }
+                    o[e] = (__bf16)v;
+                }
+                *reinterpret_cast<bf16x4 *>(X + pix * kLdX + n0) = o;
             }
         }
     }
@@ -120,19 +220,24 @@ __device__ __forceinline__ void lds_to_global(const __bf16 *X, __bf16 *__restric
     }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const Params p) {
+__global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *X = reinterpret_cast<__bf16 *>(smem);
-    float *red = reinterpret_cast<float *>(smem + kTileM * kLdX * 2);  // [256][3]
+    __bf16 *Wr = X + kTileM * kLdX;               // weight ring, 3 x 8 KB
+    float *w6s = reinterpret_cast<float *>(Wr);   // [3][256] + [512][3], last layer only (the ring is idle then)
+    float *red = w6s + 3 * kWidth;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mh = wave & 1, nh = wave >> 1;
+    const int mh = wave & 3, nh = wave >> 2;
     const int b = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - b * p.tiles_per_image) * kTileM;
     const int nvalid = min(kTileM, p.HW - p0);
     const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
+    bf16x8 q[kQueue];  // the first weight chunks are requested before anything else
+#pragma unroll
+    for (int j = 0; j < kQueue; ++j) q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<true>(p, j, tid));
 
     // ---- positional encoding of the tile (mlp2d.py:64-68): channel 2 i + j = sin(2^i pi x_j), 20 + 2 i + j = cos ----
     {
-        const int r = tid & 127, half = tid >> 7;  // half 0: sines, half 1: cosines + the zero padding
+        const int r = tid & (kTileM - 1), half = tid / kTileM;  // half 0: sines, half 1: cosines + the zero padding
         float x0 = 0.f, x1 = 0.f;
         if (r < nvalid) {
             const float2 sc = reinterpret_cast<const float2 *>(p.samplecoords)[pix0 + r];
@@ -161,41 +266,54 @@ __global__ __launch_bounds__(kThreads, 2) void fwd_kernel(const Params p) {
     }
     f32x16 acc[2][4];
     // ---- layer 1: 40 (48) -> 256, per-image bias ----
-    tile_gemm<kK0>(X, p.w1pos, acc, mh, nh, lane);
+    tile_gemm<kK0, 0, true>(X, Wr, p, q, acc, mh, nh, lane, tid);
     __syncthreads();
     acc_to_lds<true>(X, acc, p.bias1 + (size_t)b * kWidth, mh, nh, lane);
     __syncthreads();
     if (p.acts) lds_to_global(X, p.acts + pix0 * kWidth, nvalid, tid);
     // ---- layers 2..5: 256 -> 256 ----
-    for (int l = 0; l < kHidden; ++l) {
-        tile_gemm<kWidth>(X, p.wh + (size_t)l * kWidth * kWidth, acc, mh, nh, lane);
-        __syncthreads();  // every wave has read the whole tile
-        acc_to_lds<true>(X, acc, p.bh + l * kWidth, mh, nh, lane);
-        __syncthreads();
-        if (p.acts) lds_to_global(X, p.acts + ((size_t)(l + 1) * P + pix0) * kWidth, nvalid, tid);
-    }
+#define MVP_HIDDEN_LAYER(L_)                                                                              \
+    tile_gemm<kWidth, kK0 / kChunk + (L_) * (kWidth / kChunk), true>(X, Wr, p, q, acc, mh, nh, lane, tid); \
+    __syncthreads(); /* every wave has read the whole tile */                                             \
+    acc_to_lds<true>(X, acc, p.bh + (L_) * kWidth, mh, nh, lane);                                         \
+    __syncthreads();                                                                                      \
+    if (p.acts) lds_to_global(X, p.acts + ((size_t)((L_) + 1) * P + pix0) * kWidth, nvalid, tid);
+    MVP_HIDDEN_LAYER(0)
+    MVP_HIDDEN_LAYER(1)
+    MVP_HIDDEN_LAYER(2)
+    MVP_HIDDEN_LAYER(3)
+#undef MVP_HIDDEN_LAYER
     // ---- layer 6: 256 -> 3, * 25 + 100 (mlp2d.py:40,70) ----
+    for (int i = tid; i < 3 * kWidth; i += kThreads) w6s[i] = p.w6[i];  // (per-thread global loads of w6 cost 384 each)
+    __syncthreads();
     {
-        const int r = tid & 127, half = tid >> 7;
+        const int r = tid & (kTileM - 1), half = tid / kTileM;
         const __bf16 *xr = X + r * kLdX + half * 128;
-        const float *w = p.w6 + half * 128;
+        const float *w = w6s + half * 128;  // same address in every lane of a wave: LDS broadcast reads
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
         for (int k = 0; k < 128; k += 8) {
             const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(xr + k);
+            float w0[8], w1[8], w2[8];
+            *reinterpret_cast<float4 *>(w0) = *reinterpret_cast<const float4 *>(w + k);
+            *reinterpret_cast<float4 *>(w0 + 4) = *reinterpret_cast<const float4 *>(w + k + 4);
+            *reinterpret_cast<float4 *>(w1) = *reinterpret_cast<const float4 *>(w + kWidth + k);
+            *reinterpret_cast<float4 *>(w1 + 4) = *reinterpret_cast<const float4 *>(w + kWidth + k + 4);
+            *reinterpret_cast<float4 *>(w2) = *reinterpret_cast<const float4 *>(w + 2 * kWidth + k);
+            *reinterpret_cast<float4 *>(w2 + 4) = *reinterpret_cast<const float4 *>(w + 2 * kWidth + k + 4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xf = (float)xv[e];
-                s0 = fmaf(xf, w[k + e], s0), s1 = fmaf(xf, w[kWidth + k + e], s1), s2 = fmaf(xf, w[2 * kWidth + k + e], s2);
+                s0 = fmaf(xf, w0[e], s0), s1 = fmaf(xf, w1[e], s1), s2 = fmaf(xf, w2[e], s2);
             }
         }
         red[tid * 3 + 0] = s0, red[tid * 3 + 1] = s1, red[tid * 3 + 2] = s2;
     }
     __syncthreads();
-    if (tid < 128 && tid < nvalid) {
+    if (tid < kTileM && tid < nvalid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = red[tid * 3 + c] + red[(tid + 128) * 3 + c] + p.b6[c];
+            const float v = red[tid * 3 + c] + red[(tid + kTileM) * 3 + c] + p.b6[c];
             p.out[((size_t)b * 3 + c) * p.HW + p0 + tid] = v * 25.f + 100.f;
         }
     }
@@ -225,30 +343,36 @@ __device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *__restri
     }
 }
 
-// column sums of the tile: 8 threads (tid >> 5) hold partial sums of the same 8 columns -> LDS -> one row of `out`
-__device__ __forceinline__ void reduce_colsum(float *scratch /*[8][256]*/, const float (&cs)[8], float *__restrict__ out, int tid) {
+// column sums of the tile: 16 threads (tid >> 5) hold partial sums of the same 8 columns -> LDS -> one row of `out`
+__device__ __forceinline__ void reduce_colsum(float *scratch /*[16][256]*/, const float (&cs)[8], float *__restrict__ out, int tid) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) scratch[(tid >> 5) * kWidth + (tid & 31) * 8 + e] = cs[e];
     __syncthreads();
-    float s = 0.f;
+    if (tid < kWidth) {
+        float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += scratch[j * kWidth + tid];
-    out[tid] = s;
+        for (int j = 0; j < kThreads / 32; ++j) s += scratch[j * kWidth + tid];
+        out[tid] = s;
+    }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kThreads, 2) void bwd_kernel(const Params p) {
+__global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *X = reinterpret_cast<__bf16 *>(smem);
-    float *gl = reinterpret_cast<float *>(smem + kTileM * kLdX * 2);  // [128][3] upstream gradient * 25
-    float *scratch = gl + kTileM * 3;                                  // [8][256] column-sum staging
+    __bf16 *Wr = X + kTileM * kLdX;                      // weight ring, 3 x 8 KB ...
+    float *scratch = reinterpret_cast<float *>(Wr);      // ... doubling as the [16][256] column-sum staging between GEMMs
+    float *gl = reinterpret_cast<float *>(Wr + kRing * kRingElems);  // [256][3] upstream gradient * 25
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mh = wave & 1, nh = wave >> 1;
+    const int mh = wave & 3, nh = wave >> 2;
     const int b = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - b * p.tiles_per_image) * kTileM;
     const int nvalid = min(kTileM, p.HW - p0);
     const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
+    bf16x8 q[kQueue];
+#pragma unroll
+    for (int j = 0; j < kQueue; ++j) q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<false>(p, j, tid));
 
-    if (tid < 128) {
+    if (tid < kTileM) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             gl[tid * 3 + c] = tid < nvalid ? 25.f * p.grad_out[((size_t)b * 3 + c) * p.HW + p0 + tid] : 0.f;
@@ -262,15 +386,20 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_kernel(const Params p) {
         for (int e = 0; e < 8; ++e) cs[e] = 0.f;
         const __bf16 *A = p.acts + (4 * P + pix0) * kWidth;
         __bf16 *DZ = p.dz + (4 * P + pix0) * kWidth;
+        float w6r[3][8];  // this thread's 8 columns of W6 (c8 below is the same in every pass)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w6r[c][e] = p.w6[c * kWidth + (tid & 31) * 8 + e];
         for (int i = tid; i < kTileM * (kWidth / 8); i += kThreads) {
-            const int row = i >> 5, c8 = (i & 31) * 8;
+            const int row = i >> 5, c8 = (tid & 31) * 8;
             const float g0 = gl[row * 3], g1 = gl[row * 3 + 1], g2 = gl[row * 3 + 2];
             bf16x8 g;
             if (row < nvalid) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(A + (size_t)row * kWidth + c8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float da = g0 * p.w6[c8 + e] + g1 * p.w6[kWidth + c8 + e] + g2 * p.w6[2 * kWidth + c8 + e];
+                    const float da = g0 * w6r[0][e] + g1 * w6r[1][e] + g2 * w6r[2][e];
                     g[e] = (__bf16)(da * ((float)a[e] > 0.f ? 1.f : kSlope));
                     cs[e] += (float)g[e];
                 }
@@ -286,17 +415,24 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_kernel(const Params p) {
     reduce_colsum(scratch, cs, p.colsum + (4 * ntiles + blockIdx.x) * kWidth, tid);
     // ---- dZ_l = (dZ_{l+1} . W_{l+1}) * leaky'(A_l), l = 4..1 ----
     f32x16 acc[2][4];
-    for (int l = kHidden - 1; l >= 0; --l) {
-        tile_gemm<kWidth>(X, p.wh + (size_t)l * kWidth * kWidth, acc, mh, nh, lane);  // p.wh = transposed weights here
-        __syncthreads();
-        acc_to_lds<false>(X, acc, nullptr, mh, nh, lane);
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-        mask_and_store(X, p.acts + ((size_t)l * P + pix0) * kWidth, p.dz + ((size_t)l * P + pix0) * kWidth, nvalid, tid, cs);
-        __syncthreads();
-        reduce_colsum(scratch, cs, p.colsum + ((size_t)l * ntiles + blockIdx.x) * kWidth, tid);
+#define MVP_BWD_LAYER(I_)                                                                                            \
+    {                                                                                                                \
+        constexpr int l = kHidden - 1 - (I_);                                                                        \
+        tile_gemm<kWidth, (I_) * (kWidth / kChunk), false>(X, Wr, p, q, acc, mh, nh, lane, tid); /* transposed W */   \
+        __syncthreads();                                                                                             \
+        acc_to_lds<false>(X, acc, nullptr, mh, nh, lane);                                                            \
+        __syncthreads();                                                                                             \
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;                                                                     \
+        mask_and_store(X, p.acts + ((size_t)l * P + pix0) * kWidth, p.dz + ((size_t)l * P + pix0) * kWidth, nvalid,  \
+                       tid, cs);                                                                                     \
+        __syncthreads();                                                                                             \
+        reduce_colsum(scratch, cs, p.colsum + ((size_t)l * ntiles + blockIdx.x) * kWidth, tid);                      \
     }
+    MVP_BWD_LAYER(0)
+    MVP_BWD_LAYER(1)
+    MVP_BWD_LAYER(2)
+    MVP_BWD_LAYER(3)
+#undef MVP_BWD_LAYER
 }
 
 }  // namespace bgmlp
@@ -327,8 +463,8 @@ extern "C" int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const
     p.samplecoords = samplecoords, p.bias1 = bias1, p.w1pos = static_cast<const __bf16 *>(w1pos);
     p.wh = static_cast<const __bf16 *>(wh), p.bh = bh, p.w6 = w6, p.b6 = b6;
     p.acts = static_cast<__bf16 *>(acts), p.x0 = static_cast<__bf16 *>(x0), p.out = out;
-    const size_t lds = (size_t)kTileM * kLdX * 2 + kThreads * 3 * sizeof(float);
-    // 69 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU; two workgroups fit)
+    const size_t lds = (size_t)kTileM * kLdX * 2 + kRing * kRingElems * 2;
+    // 156 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
@@ -347,7 +483,7 @@ extern "C" int mvp_bgmlp_backward(int B, int HW, const float *grad_out, const vo
     if (!aligned16(acts) || !aligned16(whT) || !aligned16(dz)) return MVP_ERR_BADARG;
     p.grad_out = grad_out, p.acts = const_cast<__bf16 *>(static_cast<const __bf16 *>(acts));
     p.wh = static_cast<const __bf16 *>(whT), p.w6 = w6, p.dz = static_cast<__bf16 *>(dz), p.colsum = colsum;
-    const size_t lds = (size_t)kTileM * kLdX * 2 + (kTileM * 3 + 8 * kWidth) * sizeof(float);
+    const size_t lds = (size_t)kTileM * kLdX * 2 + kRing * kRingElems * 2 + kTileM * 3 * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);

@@ -221,9 +221,9 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
            "ms_per_iter": 1e3 * elapsed / steps, "steps": steps, "frames_per_s": N * world * steps / elapsed,
            "allreduce_mb": nparams * 4e-6 if world > 1 else 0.0, "param_mb": nparams * 4e-6,
            "kernel_ms": kernel_averages(events), "final_loss": float(state["loss"]),
-           "background_mlp": ("bf16 autocast, %.1f GFLOP fwd per iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
-           if with_bg else "off (black-free matting over a constant: 80 frames x 5 layers of 256-channel activations "
-                           "would hold ~54 GB for the backward)"}
+           "background_mlp": ("fused MFMA kernels (csrc/bgmlp.hip: bf16 operands, fp32 accumulation), %.1f GFLOP fwd per "
+                              "iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
+           if with_bg else "off (matting over a constant background)"}
     del tr, model, batch
     torch.cuda.empty_cache()
     return out
@@ -299,10 +299,14 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     if gpu and not args.no_train:
         # the reference's other logged number (ddp-train.py:446,512): iterations/s of the loop, here on the raymarch
         # training path with a stand-in decoder.  C3 = the reference's per-GPU batch shape (4 frames, K=16384) with the
-        # bf16 background MLP; C2 = the 80-frame render batch (background off, see train_leg).
+        # background MLP (fused MFMA kernels); C2 = the 80-frame render batch, background off and (C2_bg) on.
         train = {"note": "stand-in decoder (per-primitive slab parameters), NOT ava-256's conv stacks",
                  "C3": train_leg("C3", 8, 2, rank, local_rank, world, dev, dist, with_bg=True),
                  "C2": train_leg("C2", 4, 1, rank, local_rank, world, dev, dist, with_bg=False)}
+        # the 80-frame batch WITH the background MLP: its bf16 activations and their gradients for the backward are
+        # 2 x 54 GB (80 x 512 x 512 pixels x 5 layers x 256 channels) -- run when the device has the room
+        if torch.cuda.mem_get_info(dev)[0] > 160 * (1 << 30):
+            train["C2_bg"] = train_leg("C2", 3, 1, rank, local_rank, world, dev, dist, with_bg=True)
 
     if rank == 0:
         rays_per_step = cams_total * H * W

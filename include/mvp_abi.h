@@ -195,7 +195,7 @@ int mvp_grads_clip_scale(int ntensors, float *const *grads, const long long *num
  *   out    [B,3,HW] float32 (NCHW planes)
  * bf16 operands, fp32 accumulation.  Backward: dz [5, B*HW, 256] bf16 = gradients w.r.t. the five pre-activations
  * (the chain of input gradients), from grad_out [B,3,HW] and `acts`; whT holds the transposed hidden weights
- * [4,256,256] = [in][out]; colsum [5, B*ceil(HW/128), 256] float32 = column sums of dz per 128-pixel tile (tiles of one
+ * [4,256,256] = [in][out]; colsum [5, B*ceil(HW/256), 256] float32 = column sums of dz per 256-pixel tile (tiles of one
  * image are consecutive: summed over an image they are the gradient of bias1, over everything of bh).  Weight gradients
  * are [256 x P] . [P x 256] GEMMs over (x0 | acts, dz), left to the caller's BLAS. */
 int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const float *bias1, const void *w1pos, const void *wh,
