@@ -244,11 +244,13 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
             x0 = sc.x, x1 = sc.y;
         }
         __bf16 *row = X + r * kLdX + half * 20;
-        float f = 1.f;
+        // v_sin_f32 / v_cos_f32 take their argument in revolutions and reduce it exactly (|arg| <= 256 here):
+        // sin(2^i pi x) = v_sin(2^(i-1) x).  Absolute error ~1e-6, far below the bf16 rounding of the result.
+        float f = 0.5f;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            row[2 * i] = (__bf16)(half ? cospif(f * x0) : sinpif(f * x0));
-            row[2 * i + 1] = (__bf16)(half ? cospif(f * x1) : sinpif(f * x1));
+            row[2 * i] = (__bf16)(half ? __builtin_amdgcn_cosf(f * x0) : __builtin_amdgcn_sinf(f * x0));
+            row[2 * i + 1] = (__bf16)(half ? __builtin_amdgcn_cosf(f * x1) : __builtin_amdgcn_sinf(f * x1));
             f *= 2.f;
         }
         if (half) {
@@ -458,7 +460,7 @@ extern "C" int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const
     if (rc != MVP_OK) return rc;
     if (!samplecoords || !bias1 || !w1pos || !wh || !bh || !w6 || !b6 || !out) return MVP_ERR_BADARG;
     if (!aligned16(w1pos) || !aligned16(wh) || (acts && !aligned16(acts)) || (x0 && !aligned16(x0)) ||
-        ((uintptr_t)samplecoords & 7u))
+        !aligned16(bias1) || !aligned16(bh) || ((uintptr_t)samplecoords & 7u))
         return MVP_ERR_BADARG;
     p.samplecoords = samplecoords, p.bias1 = bias1, p.w1pos = static_cast<const __bf16 *>(w1pos);
     p.wh = static_cast<const __bf16 *>(wh), p.bh = bh, p.w6 = w6, p.b6 = b6;

@@ -302,7 +302,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         # background MLP (fused MFMA kernels); C2 = the 80-frame render batch, background off and (C2_bg) on.
         train = {"note": "stand-in decoder (per-primitive slab parameters), NOT ava-256's conv stacks",
                  "C3": train_leg("C3", 8, 2, rank, local_rank, world, dev, dist, with_bg=True),
-                 "C2": train_leg("C2", 4, 1, rank, local_rank, world, dev, dist, with_bg=False)}
+                 "C2": train_leg("C2", 6, 2, rank, local_rank, world, dev, dist, with_bg=False)}
         # the 80-frame batch WITH the background MLP: its bf16 activations and their gradients for the backward are
         # 2 x 54 GB (80 x 512 x 512 pixels x 5 layers x 256 channels) -- run when the device has the room
         if torch.cuda.mem_get_info(dev)[0] > 160 * (1 << 30):

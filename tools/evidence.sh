@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/evidence.sh <tag> -- the per-round evidence run on the GPU box (via gpurun): rocprofv3 kernel stats of the default
 # bench line, separate FETCH_SIZE / WRITE_SIZE / SQ / TA / LDS counter passes of the march kernels, and kernel stats + MFMA
-# counters of the train leg (C3: 4 frames, bf16 background MLP).  Everything lands in gpurun_out/<tag>*/ ; copy what is to
+# counters of the train leg (C3: 4 frames, fused bf16 background MLP), the MLP and warp-field microbenchmarks.  Everything lands in gpurun_out/<tag>*/ ; copy what is to
 # be judged into profiles/.
 set -u
 TAG=$1
@@ -25,4 +25,7 @@ out = [rows[0]] + [[r[0][:110]] + r[1:] for r in rows[1:40]]
 csv.writer(open(sys.argv[1], "w")).writerows(out)
 for r in out[:12]: print(" | ".join(x[:60] for x in r[:5]))
 PY
+timeout 300 python tools/bench_bgmlp_fused.py 4 512 512 > $O/bgmlp_bench.json 2>/dev/null; cat $O/bgmlp_bench.json
+timeout 300 python tools/bench_warp.py 4 512 512 4096 > $O/warp_bench.json 2>/dev/null; cat $O/warp_bench.json
+bash tools/pmc_cmd.sh ${TAG}_bgmlp "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" bgmlp -- python tools/bench_bgmlp_fused.py 4 512 512 > $O/bgmlp_pmc.log 2>&1; tail -3 $O/bgmlp_pmc.log
 cut -c1-200 $O/bench.json
