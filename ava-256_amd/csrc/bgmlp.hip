@@ -106,8 +106,10 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
     constexpr int NC = K / kChunk, GT = FWD ? kFwdChunks : kBwdChunks;
     const int lr = lane & 31, lk = (lane >> 5) * 8;
     const __bf16 *xa = X + (64 * mq + lr) * kLdX + lk;
-    __bf16 *dst = Wr + tid * 8;
-    const __bf16 *wb = Wr + (128 * nh + lr) * kChunk + lk;
+    // ring buffer layout [k-half][n][8]: a wave's fragment read (32 consecutive n, one k-half per half-wave) is two
+    // contiguous 512-byte blocks = conflict-free; with [n][16] the 16 lanes of a pass were 32 bytes apart (2-way conflicts)
+    __bf16 *dst = Wr + ((tid & 1) * kWidth + (tid >> 1)) * 8;
+    const __bf16 *wb = Wr + ((lane >> 5) * kWidth + 128 * nh + lr) * 8;
 #define MVP_STAGE(G_)                                                                                         \
     {                                                                                                         \
         *reinterpret_cast<bf16x8 *>(dst + ((G_) % kRing) * kRingElems) = q[(G_) % kQueue];                    \
@@ -117,7 +119,7 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
 #define MVP_FRAGS(A_, B_, C_)                                                                                 \
     {                                                                                                         \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) B_[ni] =                                             \
-            *reinterpret_cast<const bf16x8 *>(wb + ((G0 + (C_)) % kRing) * kRingElems + ni * 32 * kChunk);    \
+            *reinterpret_cast<const bf16x8 *>(wb + ((G0 + (C_)) % kRing) * kRingElems + ni * 32 * 8);         \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) A_[mi] =                                             \
             *reinterpret_cast<const bf16x8 *>(xa + mi * 32 * kLdX + (C_) * kChunk);                           \
     }
