@@ -228,9 +228,16 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     __bf16 *Wr = X + kTileM * kLdX;               // weight ring, 3 x 8 KB
     float *w6s = reinterpret_cast<float *>(Wr);   // [3][256] + [512][3], last layer only (the ring is idle then)
     float *red = w6s + 3 * kWidth;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
+    // persistent: one workgroup per CU walks its share of the tiles (a launch per tile cost ~4 us of setup each)
+    for (int tile = blockIdx.x; tile < p.B * p.tiles_per_image; tile += gridDim.x) {
+    // (opaque per iteration: otherwise the ~70 per-thread weight-chunk addresses are hoisted out of the tile loop as
+    //  loop invariants and spilled)
+    int tid = tid0;
+    asm volatile("; per-tile thread index" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int mh = wave & 3, nh = wave >> 2;
-    const int b = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - b * p.tiles_per_image) * kTileM;
+    const int b = tile / p.tiles_per_image, p0 = (tile - b * p.tiles_per_image) * kTileM;
     const int nvalid = min(kTileM, p.HW - p0);
     const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
     bf16x8 q[kQueue];  // the first weight chunks are requested before anything else
@@ -321,6 +328,8 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
             p.out[((size_t)b * 3 + c) * p.HW + p0 + tid] = v * 25.f + 100.f;
         }
     }
+    __syncthreads();  // the next tile overwrites X and the ring scratch
+    }
 }
 
 // dst tile (LDS, bf16) *= leaky'(A) with A from global; result also to global dz
@@ -367,9 +376,13 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
     __bf16 *Wr = X + kTileM * kLdX;                      // weight ring, 3 x 8 KB ...
     float *scratch = reinterpret_cast<float *>(Wr);      // ... doubling as the [16][256] column-sum staging between GEMMs
     float *gl = reinterpret_cast<float *>(Wr + kRing * kRingElems);  // [256][3] upstream gradient * 25
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
+    for (int tile = blockIdx.x; tile < p.B * p.tiles_per_image; tile += gridDim.x) {
+    int tid = tid0;
+    asm volatile("; per-tile thread index" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int mh = wave & 3, nh = wave >> 2;
-    const int b = blockIdx.x / p.tiles_per_image, p0 = (blockIdx.x - b * p.tiles_per_image) * kTileM;
+    const int b = tile / p.tiles_per_image, p0 = (tile - b * p.tiles_per_image) * kTileM;
     const int nvalid = min(kTileM, p.HW - p0);
     const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
     bf16x8 q[kQueue];
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
         }
     }
     __syncthreads();
-    reduce_colsum(scratch, cs, p.colsum + (4 * ntiles + blockIdx.x) * kWidth, tid);
+    reduce_colsum(scratch, cs, p.colsum + (4 * ntiles + tile) * kWidth, tid);
     // ---- dZ_l = (dZ_{l+1} . W_{l+1}) * leaky'(A_l), l = 4..1 ----
     f32x16 acc[2][4];
 #define MVP_BWD_LAYER(I_)                                                                                            \
@@ -430,17 +443,27 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
         mask_and_store(X, p.acts + ((size_t)l * P + pix0) * kWidth, p.dz + ((size_t)l * P + pix0) * kWidth, nvalid,  \
                        tid, cs);                                                                                     \
         __syncthreads();                                                                                             \
-        reduce_colsum(scratch, cs, p.colsum + ((size_t)l * ntiles + blockIdx.x) * kWidth, tid);                      \
+        reduce_colsum(scratch, cs, p.colsum + ((size_t)l * ntiles + tile) * kWidth, tid);                           \
     }
     MVP_BWD_LAYER(0)
     MVP_BWD_LAYER(1)
     MVP_BWD_LAYER(2)
     MVP_BWD_LAYER(3)
 #undef MVP_BWD_LAYER
+    }  // (reduce_colsum ends with a barrier: X, ring and gl are free for the next tile)
 }
 
 }  // namespace bgmlp
 }  // namespace mvp
+
+// one workgroup per CU (its 156 KB of LDS fills the CU), each walking tiles blockIdx.x, blockIdx.x + grid, ...
+static int persistent_grid(int ntiles) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    return ntiles < cus ? ntiles : cus;
+}
 
 static int bgmlp_common(int B, int HW, mvp::bgmlp::Params &p) {
     if (B < 0 || HW < 0) return MVP_ERR_BADARG;
@@ -471,7 +494,7 @@ extern "C" int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const
     // 156 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)persistent_grid(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
     return launch_status();
 }
 
@@ -490,6 +513,6 @@ extern "C" int mvp_bgmlp_backward(int B, int HW, const float *grad_out, const vo
     const size_t lds = (size_t)kTileM * kLdX * 2 + kRing * kRingElems * 2 + kTileM * 3 * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)persistent_grid(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
     return launch_status();
 }
