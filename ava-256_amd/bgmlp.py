@@ -34,7 +34,14 @@ class _FusedBgMlp(torch.autograd.Function):
         # hidden = (W2, b2, W3, b3, W4, b4, W5, b5): weights [256,256] ([out][in]), biases [256]
         if not samplecoords.is_cuda:
             raise RuntimeError("fused background MLP: CUDA/HIP tensors only (no CPU fallback)")
+        if samplecoords.dim() != 4 or samplecoords.shape[-1] != 2:
+            raise ValueError("samplecoords must be [B,H,W,2]")
         B, H, W = samplecoords.shape[:3]
+        if (len(hidden) != 2 * HIDDEN or tuple(w1pos.shape) != (WIDTH, POS) or tuple(w6.shape) != (3, WIDTH)
+                or tuple(bias1.shape) != (B, WIDTH) or tuple(b6.shape) != (3,)
+                or any(tuple(hidden[2 * i].shape) != (WIDTH, WIDTH) or tuple(hidden[2 * i + 1].shape) != (WIDTH,)
+                       for i in range(HIDDEN))):
+            raise ValueError("fused background MLP: the kernels are built for 40 -> 256 x 5 -> 3 (mlp2d.py:29-41)")
         HW, dev = H * W, samplecoords.device
         sc = samplecoords.detach().float().contiguous()
         w1p = torch.zeros((WIDTH, POS_PAD), device=dev, dtype=torch.bfloat16)

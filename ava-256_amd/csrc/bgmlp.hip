@@ -85,7 +85,10 @@ __device__ __forceinline__ const __bf16 *chunk_ptr(const Params &p, int g, int t
 }
 constexpr int kFwdChunks = kK0 / kChunk + kHidden * (kWidth / kChunk);  // 67
 constexpr int kBwdChunks = kHidden * (kWidth / kChunk);                 // 64
-constexpr int kQueue = 4;  // chunks in flight per thread (registers), i.e. an L2 round trip is covered by ~4 k-steps of MFMA
+#ifndef BG_QUEUE
+#define BG_QUEUE 4
+#endif
+constexpr int kQueue = BG_QUEUE;  // chunks in flight per thread (registers), i.e. an L2 round trip is covered by ~4 k-steps of MFMA
 
 // acc[mi][ni] = (X[64 mq + 32 mi .., :K] . W[128 nh + 32 ni .., :K]^T)^T for the layer whose weights are chunks
 // G0 .. G0 + K/16 - 1 of the stream.  The MFMA is issued with the WEIGHT fragment as A and the activation fragment as B,
