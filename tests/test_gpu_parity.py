@@ -187,8 +187,9 @@ def test_non_cubic_slabs_and_general_fade(ops, oracle64, shape, fadescale, fadee
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("MVP_FUZZ_SEEDS", "10")))))  # more with MVP_FUZZ_SEEDS=n
 def test_randomized_configurations(ops, oracle64, seed):
     """Seeded random draws over image size (ragged packets), primitive count (non powers of two, tiny), slab shape,
-    opacity (none to most rays saturating), box size, step size and fade parameters; forward and all gradients against
-    the float64 oracle with the standing tolerances, backward owner chosen at random as well."""
+    opacity (none to most rays saturating), box size, step size and fade parameters, and -- one draw in four -- a warp
+    field (algo 1) on a random grid; forward and all gradients against the float64 oracle with the standing tolerances,
+    backward owner chosen at random as well."""
     from ava256_amd.scene import make_scene
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.integers(1, 4))
@@ -204,22 +205,31 @@ def test_randomized_configurations(ops, oracle64, seed):
     TD, TH, TW = shape
     tpl = np.concatenate([np.maximum(100 + 25 * rng.normal(size=(N, K, TD, TH, TW, 3)), 0),
                           again * np.exp(0.1 * rng.normal(size=(N, K, TD, TH, TW, 1)))], axis=-1)
+    warp = None
+    if rng.random() < 0.25:  # identity grid + noise, WD x WH x WW nodes
+        WD, WH, WW = (int(x) for x in rng.integers(2, 9, size=3))
+        zz, yy, xx = np.meshgrid(np.linspace(-1, 1, WD), np.linspace(-1, 1, WH), np.linspace(-1, 1, WW), indexing="ij")
+        warp = np.stack([xx, yy, zz], -1)[None, None] + float(rng.choice([0.05, 0.3])) * rng.normal(size=(N, K, WD, WH, WW, 3))
     rp, rd, tm = scene_rays(oracle64, s)
     a = (rp, rd, stepsize, tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), tpl)
-    ref_rgba, ref_sat, st = oracle64.march_forward(*a, fadescale=fadescale, fadeexp=fadeexp, ray_diagnostics=True)
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, fadescale=fadescale, fadeexp=fadeexp, ray_diagnostics=True, warp=warp)
     if st["rays_hit"] == 0 or st["list_overflow"] > 0:
         pytest.skip("degenerate draw")
     gout = rng.normal(size=ref_rgba.shape)
     fragile = FragileRays(ref_sat, st["margin"], gout, max_frac=0.01, min_allowed=3)
-    rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, mode=mode)
+    rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, mode=mode, warp=warp)
     fr = fragile.mask
-    cfg = "seed %d: N%d %dx%d K%d slab%s gain%g fade(%g,%g) dt%g mode %s" % (seed, N, H, W, K, shape, again, fadescale,
-                                                                          fadeexp, stepsize, mode)
+    cfg = "seed %d: N%d %dx%d K%d slab%s gain%g fade(%g,%g) dt%g mode %s warp %s" % (
+        seed, N, H, W, K, shape, again, fadescale, fadeexp, stepsize, mode, None if warp is None else warp.shape[2:5])
     g2 = fragile.masked()
-    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, g2, fadescale=fadescale, fadeexp=fadeexp)
+    ref = oracle64.march_backward(*a, ref_sat, g2, fadescale=fadescale, fadeexp=fadeexp, warp=warp)
+    rgp, rgr, rgs, rgt = ref[:4]
     err = np.abs(rgba - ref_rgba).max(-1)
     assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0, (cfg, err[~fr].max())
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), cfg)
+    if warp is not None:  # a position gradient like the pose gradients (see the warp-field tests below for the bounds)
+        gw, rgw = grads["warp"], ref[4]
+        assert cosine(gw, rgw) >= POSE_COS and np.linalg.norm(gw - rgw) <= 2e-2 * np.linalg.norm(rgw), (cfg, cosine(gw, rgw))
 
 
 @pytest.mark.parametrize("mode", BACKWARD_MODES)
