@@ -461,10 +461,12 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
 
 // one workgroup per CU (its 156 KB of LDS fills the CU), each walking tiles blockIdx.x, blockIdx.x + grid, ...
 static int persistent_grid(int ntiles) {
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
     return ntiles < cus ? ntiles : cus;
 }
 
