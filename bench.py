@@ -182,7 +182,13 @@ def make_march_step_gpu(args, rank, world, dev):
         rgba.backward(gout)
         return rgba
 
-    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N}
+    def render():  # inference: no gradients, rays made inside the march (row N1), nothing handed to a backward
+        with torch.no_grad():
+            return ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"],
+                                                volradius, stepsize, (s["primpos"], s["primrot"], s["primscale"]),
+                                                s["template"])
+
+    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render}
 
 
 def kernel_averages(events):
@@ -286,6 +292,17 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     else:
         elapsed = run_timed(step, args.steps, args.warmup, dist, dev)
     kavg = kernel_averages(events)
+    render_ms = None
+    if gpu and "render" in info:  # the forward alone as a renderer would call it (extra field, not the contract value)
+        for _ in range(2):
+            info["render"]()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            info["render"]()
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        render_ms = ev0.elapsed_time(ev1) / 5
 
     # rays of all ranks per step: every rank contributes its own shard (gathered, so that uneven strong-scaling
     # shards are counted exactly)
@@ -346,6 +363,9 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                     traffic = None
             out["fwd_rays_per_s"] = (info["n_local"] * H * W) / (kavg["march_forward"] * 1e-3) if "march_forward" in kavg else None
             out["kernel_ms"] = kavg
+            if render_ms is not None:
+                out["render"] = {"what": "no-grad forward with rays made inside the march (mvp_march_forward_cams), this rank",
+                                 "ms": render_ms, "rays_per_s": info["n_local"] * H * W / (render_ms * 1e-3)}
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
