@@ -247,6 +247,8 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     ap.add_argument("--alpha-gain", type=float, default=1.0, help="1.0 = random-init opacity (nothing saturates)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train leg (profiling runs of the march kernels)")
+    ap.add_argument("--no-render", action="store_true", help="skip the no-grad render timing (profiling runs: keeps the "
+                                                             "per-kernel averages those of the training-path launches)")
     ap.add_argument("--mode", default="march", choices=["march", "train"],
                     help="march (default, the contract metric + a `train` object); train: only the training loop, as "
                          "the headline value (iterations/s)")
@@ -293,7 +295,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         elapsed = run_timed(step, args.steps, args.warmup, dist, dev)
     kavg = kernel_averages(events)
     render_ms = None
-    if gpu and "render" in info:  # the forward alone as a renderer would call it (extra field, not the contract value)
+    if gpu and "render" in info and not args.no_render:  # the forward alone as a renderer would call it (extra field, not the contract value)
         for _ in range(2):
             info["render"]()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

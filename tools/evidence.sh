@@ -7,8 +7,8 @@ set -u
 TAG=$1
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
-bash tools/prof.sh $TAG --steps 5 --warmup 2 --no-cpu-baseline --no-train > $O/prof.log 2>&1; tail -6 $O/prof.log
-M="--steps 3 --warmup 1 --no-cpu-baseline --no-train"
+bash tools/prof.sh $TAG --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-render > $O/prof.log 2>&1; tail -6 $O/prof.log
+M="--steps 3 --warmup 1 --no-cpu-baseline --no-train --no-render"
 bash tools/pmc.sh ${TAG}_fetch "FETCH_SIZE" $M > $O/fetch.log 2>&1
 bash tools/pmc.sh ${TAG}_write "WRITE_SIZE" $M > $O/write.log 2>&1
 bash tools/pmc.sh ${TAG}_sq "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" $M > $O/sq.log 2>&1
