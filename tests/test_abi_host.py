@@ -87,6 +87,13 @@ def test_argument_validation_happens_before_any_device_work(lib):
     bw[3] = 0
     bw[4] = bw[5] = bw[7] = p16
     assert lib.mvp_march_backward(*bw) == 0                # K == 0: nothing to differentiate
+    # fused background MLP: B, HW | samplecoords, bias1, w1pos, wh, bh, w6, b6, acts, x0, out | stream
+    assert lib.mvp_bgmlp_forward(-1, 4, *([null] * 11)) == -1
+    assert lib.mvp_bgmlp_forward(0, 4, *([null] * 11)) == 0                       # no pixels: nothing to do
+    assert lib.mvp_bgmlp_forward(1, 4, *([null] * 11)) == -1                      # null pointers
+    assert lib.mvp_bgmlp_forward(1, 4, p16, p16, p16 + 2, p16, p16, p16, p16, null, null, p16, null) == -1   # misaligned weights
+    assert lib.mvp_bgmlp_backward(1, 4, *([null] * 7)) == -1
+    assert lib.mvp_bgmlp_backward(0, 0, *([null] * 7)) == 0
 
 
 def test_operator_surface_mirrors_the_reference():

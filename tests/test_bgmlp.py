@@ -98,3 +98,16 @@ def test_fused_kernels_match_eager_fp32_on_ragged_images(shape):
         mine, eager = np.linalg.norm(g1[k] - g0[k]) / n0, np.linalg.norm(g2[k] - g0[k]) / n0
         assert _cos(g1[k], g0[k]) >= 0.99, (k, _cos(g1[k], g0[k]))
         assert mine <= 1.25 * eager + 1e-2, (k, mine, eager)
+
+
+@pytest.mark.gpu
+def test_inference_path_equals_training_path():
+    """Without gradients nothing is kept for a backward (acts / x0 are NULL in the C ABI): same kernel, same output bits."""
+    m, g = _load("cuda")
+    cam, idx = torch.from_numpy(g["camindex"]).cuda(), torch.from_numpy(g["idindex"]).cuda()
+    sc = torch.from_numpy(g["samplecoords"]).cuda()
+    with torch.no_grad():
+        a = m(cam, idx, sc)
+    b = m(cam, idx, sc)
+    assert b.requires_grad and not a.requires_grad
+    assert torch.equal(a, b.detach())
