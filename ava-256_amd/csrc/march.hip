@@ -113,6 +113,32 @@ constexpr uint32_t kFlagBwdHandoff = 4u;    // THIS backward handed a primitive 
 constexpr uint32_t kCountDead = 0x80000000u;  // pl_count bit 31: "handed over by this backward" (cleared per call)
 constexpr uint32_t kNoSat = 0xffffffffu;
 
+// Streaming traffic is marked non-temporal so that it does not push re-used lines out of the L2: in the backward a
+// primitive's slab is read once and its gradient written once per launch (5.4 GB at C2) while the ray records the same
+// workgroups gather are re-read by the ~7 primitives a ray crosses; in the forward the rays are read once and the
+// hand-off records (raysat, rayaux) are not read again before the backward, while slab lines are shared by neighbouring
+// packets.
+#ifdef MVP_NO_STREAM_HINTS
+#define MVP_STREAM_LOAD(P_) (*(P_))
+#define MVP_STREAM_STORE(P_, V_) (*(P_) = (V_))
+#define MVP_STREAM_LOADF(P_) (*(P_))
+#define MVP_STREAM_STOREF(P_, V_) (*(P_) = (V_))
+#else
+typedef __attribute__((ext_vector_type(4))) float nt_f4;  // (the builtins take native vectors, not HIP's float4 class)
+__device__ __forceinline__ float4 stream_load(const float4 *p) {
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stream_store(float4 *p, float4 g) {
+    const nt_f4 v = {g.x, g.y, g.z, g.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_f4 *>(p));
+}
+#define MVP_STREAM_LOAD(P_) stream_load(P_)
+#define MVP_STREAM_STORE(P_, V_) stream_store((P_), (V_))
+#define MVP_STREAM_LOADF(P_) __builtin_nontemporal_load(P_)
+#define MVP_STREAM_STOREF(P_, V_) __builtin_nontemporal_store((V_), (P_))
+#endif
+
 typedef float v2f __attribute__((ext_vector_type(2)));  // -> v_pk_mul_f32 / v_pk_fma_f32
 
 // Raise flag bits in a shared word without queueing behind every other wave that raises the same bits (same-address
@@ -502,11 +528,11 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                                              cload(fo), cload(fo + 1), cload(pc2), cload(pc2 + 1), fpx, fpy, p.volradius);
             o = c.o, d = c.d, tmin = c.tmin, tmax = c.tmax;
         } else {
-            o = ld3(p.raypos + r * 3);
-            d = ld3(p.raydir + r * 3);
-            const float2 tt = reinterpret_cast<const float2 *>(p.tminmax)[r];
-            tmin = tt.x;
-            tmax = tt.y;
+            const float *op = p.raypos + r * 3, *dp = p.raydir + r * 3, *tp = p.tminmax + r * 2;
+            o = mk3(MVP_STREAM_LOADF(op), MVP_STREAM_LOADF(op + 1), MVP_STREAM_LOADF(op + 2));
+            d = mk3(MVP_STREAM_LOADF(dp), MVP_STREAM_LOADF(dp + 1), MVP_STREAM_LOADF(dp + 2));
+            tmin = MVP_STREAM_LOADF(tp);
+            tmax = MVP_STREAM_LOADF(tp + 1);
         }
     }
     // a ray can only take a sample at t in [tmin, tmax + 1e-5) (subset_kernel.h:63-64,84)
@@ -1362,10 +1388,13 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
     if (!BWD && inimg) {
         reinterpret_cast<float4 *>(p.rayrgba)[r] = rgba;  // primaccum.h:51-56
-        if (p.raysat) st3(p.raysat + r * 3, raysat);
+        if (p.raysat) {
+            float *sp = p.raysat + r * 3;
+            MVP_STREAM_STOREF(sp, raysat.x), MVP_STREAM_STOREF(sp + 1, raysat.y), MVP_STREAM_STOREF(sp + 2, raysat.z);
+        }
         if (p.rayaux)
-            reinterpret_cast<uint4 *>(p.rayaux)[r] =
-                make_uint4(satkey, __float_as_uint(wbefore), (uint32_t)incs, __float_as_uint(tend));
+            MVP_STREAM_STORE(reinterpret_cast<float4 *>(p.rayaux) + r,
+                             make_float4(__uint_as_float(satkey), wbefore, __uint_as_float((uint32_t)incs), tend));
     }
 }
 
@@ -1586,7 +1615,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
     if (TS == 8) {
 #pragma unroll
         for (int i = 0; i < kVoxPerThread; ++i)
-            tv[i] = (tid + i * kPrimBlock < 512) ? T4[tid + i * kPrimBlock] : make_float4(0.f, 0.f, 0.f, 0.f);
+            tv[i] = (tid + i * kPrimBlock < 512) ? MVP_STREAM_LOAD(T4 + tid + i * kPrimBlock) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
@@ -2248,7 +2277,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                 const float4 o_ = gT4l[v];
                 g.x = o_.x + g.x, g.y = o_.y + g.y, g.z = o_.z + g.z, g.w = o_.w + g.w;
             }
-            gT4l[v] = g;
+            MVP_STREAM_STORE(gT4l + v, g);
         }
     }
     if constexpr (WARP) {  // grad_warp, written exactly once
