@@ -90,7 +90,10 @@ struct MarchParams {
     int pl_cap;
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
     int prim_lds_base;    // bwd_prim_kernel<.., WARP>: byte offset of the warp-field arrays in its dynamic LDS
-    int total_packets;    // 8 * chunk * N
+    int total_packets;    // blocks of the march grid: images_whole * 8 * chunk + 8 * chunk * (N - images_whole)
+    int images_whole;     // the first N - N % 8 images: XCD x owns images x, x + 8, ... whole
+    int band_split;       // the other R = N % 8 images: each is cut into F = band_split bands (8, 4, 2, 1 for R = 1, 2, <= 4, > 4),
+    int band_chunk;       //   ceil(T / F) packets each; 8 / F images are in flight at a time, one XCD per band
     // Only read by builds with -DMVP_DEBUG_HOOKS (tools/exp_variants.sh); the product library ignores the environment.
     int debug_force_dfs;  // MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
     int debug_slot_sweep; // MVP_DEBUG_SLOT_SWEEP=1 makes every packet take the slot-synchronous forward sweep
@@ -112,6 +115,9 @@ constexpr uint32_t kFlagGlobal = 2u;        // a packet produced step indices th
 constexpr uint32_t kFlagBwdHandoff = 4u;    // THIS backward handed a primitive to the ray-centric kernel (cleared per call)
 constexpr uint32_t kCountDead = 0x80000000u;  // pl_count bit 31: "handed over by this backward" (cleared per call)
 constexpr uint32_t kNoSat = 0xffffffffu;
+#ifndef MVP_STRIP_ROWS
+#define MVP_STRIP_ROWS 3  // packet rows per dispatch strip (march_packet: packet -> (image, tile))
+#endif
 
 // Streaming traffic is marked non-temporal so that it does not push re-used lines out of the L2: in the backward a
 // primitive's slab is read once and its gradient written once per launch (5.4 GB at C2) while the ray records the same
@@ -496,30 +502,40 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt(lane);
 
-    // ---- packet -> (image, tile): block b runs on XCD b % 8 (MI355X_MICROARCH "Workgroup dispatch"); give every
-    //      XCD a contiguous run of `chunk` row-major packets of each image so its private L2 sees a compact band.
-    const int xcd = b & 7, i = b >> 3;
-    const int n = i / p.chunk;
-    int tidx = xcd * p.chunk + (i - n * p.chunk);
-#ifndef MVP_NO_STRIP_ORDER
-    // Inside the band, full strips of MVP_STRIP_ROWS packet rows are walked column by column: the packets that share a
-    // primitive's slab (it spans ~2 x 2 packets at C2) are then dispatched a few blocks apart instead of a row (64
-    // blocks) apart.  Measured forward at C2 / C3 / C4 (ms): row-major 7.51 / 0.812 / 1.122; strips of 2: 7.01 / 0.824 /
-    // 1.134; 3: 7.04 / 0.808 / 1.128; 4: 7.03 / 0.845 / 1.228; 8: 7.15 / 0.848 / 1.22.  (HBM fetch volume and L1->L2
-    // request count are unchanged at C2: the gain is in when the shared lines are asked for, not in how often.)
-    {
-#ifndef MVP_STRIP_ROWS
-#define MVP_STRIP_ROWS 3
-#endif
-        const int j = i - n * p.chunk, S = MVP_STRIP_ROWS * p.tiles_x;
-        const int base = j - j % S, first = xcd * p.chunk + base;
-        if (first % p.tiles_x == 0 && base + S <= p.chunk && first + S <= p.tiles_x * p.tiles_y) {
-            const int jj = j - base;
-            tidx = first + (jj % MVP_STRIP_ROWS) * p.tiles_x + (jj / MVP_STRIP_ROWS);
-        }
+    // ---- packet -> (image, tile).  Block b runs on XCD b % 8 (MI355X_MICROARCH "Workgroup dispatch"), so the block
+    // index decides which XCD renders what, statically.  An image is a sequence of strips (MVP_STRIP_ROWS packet rows,
+    // walked column by column: the packets that share a primitive's slab -- it spans ~2 x 2 packets at C2 -- start a few
+    // blocks apart instead of a row apart).  F XCDs share an image by taking its strips cyclically, 8 / F images are in
+    // flight at a time:
+    //   * the first N - N % 8 images: F = 1, XCD x renders images x, x + 8, ... whole;
+    //   * the other R = N % 8 images (all of them when N < 8): F = 8, 4, 2, 1 for R = 1, 2, 3..4, 5..7.
+    // Why: the first version gave XCD x the x-th horizontal BAND of every image -- the top and bottom bands of a head
+    // shot are background, so two XCDs idled while the two middle ones carried the kernel (same total wave-cycles, 30 %
+    // longer wall time).  C2 forward 7.51 ms (bands, row-major) -> 7.04 (bands, strips) -> 5.30 (whole images); C3 / C4
+    // (N = 4) 0.81 / 1.12 -> 0.70 / 0.93 with two half-image bands per image -> see DESIGN.md 3.3 for the cyclic form.
+    const int T8 = 8 * p.chunk, blocks_whole = p.images_whole * T8;
+    int n, j, F, band;  // image, packet slot inside this XCD's share of the image, XCDs per image, which of them
+    if (b < blocks_whole) {
+        const int xcd = b & 7, i = b >> 3, q = i / T8;
+        n = q * 8 + xcd, j = i - q * T8, F = 1, band = 0;
+    } else {
+        const int bb = b - blocks_whole, xcd = bb & 7, i = bb >> 3, q = i / p.band_chunk;
+        F = p.band_split, band = xcd % F;
+        n = p.images_whole + q * (8 / F) + xcd / F, j = i - q * p.band_chunk;
+        if (n >= p.N) return;
     }
+    int tidx;
+    {
+        const int S = MVP_STRIP_ROWS * p.tiles_x;          // packet slots per strip
+        const int strip = (j / S) * F + band, jj = j % S;  // the strip of the image, the slot inside it
+        const int row0 = strip * MVP_STRIP_ROWS, rows = min(MVP_STRIP_ROWS, p.tiles_y - row0);
+        if (rows <= 0 || jj >= rows * p.tiles_x) return;   // (a ragged last strip leaves some slots empty)
+#ifndef MVP_NO_STRIP_ORDER
+        tidx = (row0 + jj % rows) * p.tiles_x + jj / rows;
+#else
+        tidx = row0 * p.tiles_x + jj;
 #endif
-    if (tidx >= p.tiles_x * p.tiles_y) return;
+    }
     const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
     const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
     const bool inimg = px < p.W && py < p.H;
@@ -1603,12 +1619,21 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int K = p.K;
-    // XCD-aware: block b runs on XCD b % 8; give each XCD a contiguous range of k (neighbours on the shell share rays)
-    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
-    const int chunkk = (K + 7) >> 3;
-    const int n = i / chunkk;
-    const int k = xcd * chunkk + (i - n * chunkk);
-    if (k >= K) return;
+    // XCD-aware (block b runs on XCD b % 8): XCD x owns ALL primitives of images x, x + 8, ... of the first N - N % 8
+    // images -- an image's ray records, which ~7 of its primitives re-read, then live in one L2 instead of eight; the
+    // remaining R images are split over F = band_split XCDs each (contiguous ranges of k: neighbours on the shell share
+    // rays), 8 / F images at a time (see march_packet).
+    const int b = blockIdx.x, blocks_whole = p.images_whole * K;
+    int n, k;
+    if (b < blocks_whole) {
+        const int xcd = b & 7, i = b >> 3, q = i / K;
+        n = q * 8 + xcd, k = i - q * K;
+    } else {
+        const int bb = b - blocks_whole, xcd = bb & 7, i = bb >> 3;
+        const int F = p.band_split, chunkk = (K + F - 1) / F, q = i / chunkk;
+        n = p.images_whole + q * (8 / F) + xcd / F, k = (xcd % F) * chunkk + (i - q * chunkk);
+        if (n >= p.N || k >= K) return;
+    }
     const size_t pk = (size_t)n * K + k;
     uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] reserved, [2] bits(Rmax); then per-packet bits(max |g|)
     const uint32_t *pmax_n = tail + 3 + (size_t)n * p.tiles_x * p.tiles_y;
@@ -2359,8 +2384,16 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     p.tiles_x = (p.W + kTile - 1) / kTile;
     p.tiles_y = (p.H + kTile - 1) / kTile;
     const long long T = (long long)p.tiles_x * p.tiles_y;
-    p.chunk = (int)((T + 7) / 8);
-    const long long blocks = 8ll * p.chunk * p.N;
+    // packet slots: an image is ceil(tiles_y / MVP_STRIP_ROWS) strips of MVP_STRIP_ROWS * tiles_x slots (march_packet)
+    const long long strips = (p.tiles_y + MVP_STRIP_ROWS - 1) / MVP_STRIP_ROWS, S = (long long)MVP_STRIP_ROWS * p.tiles_x;
+    if (strips * S > 0x3fffffffll) return MVP_ERR_UNSUPPORTED;
+    p.chunk = (int)((strips * S + 7) / 8);            // 8 * chunk >= the slots of a whole image
+    p.images_whole = p.N - p.N % 8;
+    const int R = p.N - p.images_whole;
+    p.band_split = R == 0 ? 8 : R == 1 ? 8 : R == 2 ? 4 : R <= 4 ? 2 : 1;
+    p.band_chunk = (int)(((strips + p.band_split - 1) / p.band_split) * S);  // slots of one XCD's share of an image
+    const int rounds = (R * p.band_split + 7) / 8;  // groups of 8 / F images
+    const long long blocks = 8ll * p.chunk * p.images_whole + 8ll * p.band_chunk * rounds;
     if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
     p.total_packets = (int)blocks;
 #ifdef MVP_DEBUG_HOOKS
@@ -2536,7 +2569,8 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         if (norays) return MVP_OK;
         p.fallback_all = 1;
     } else {
-        const long long pb = 8ll * ((K + 7) / 8) * N;
+        const long long pb = (long long)p.images_whole * K +
+                             8ll * ((K + p.band_split - 1) / p.band_split) * (((N - p.images_whole) * p.band_split + 7) / 8);
         if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
         // bounds for the fixed-point scales: per-packet max |grad_rayrgba| behind the tail of primlist_count (max |raysat|
         // is in the tail already, written by the forward); also clears what an earlier backward left behind

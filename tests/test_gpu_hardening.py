@@ -177,6 +177,33 @@ def test_warp_field_backward_is_reproducible(ops):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+@pytest.mark.parametrize("N", [5, 8, 10, 17])
+def test_block_to_image_mapping_with_eight_or_more_images(ops, oracle64, N, mode):
+    """Blocks are mapped to (image, packet) / (image, primitive) in two regimes: the first N - N % 8 images go whole to
+    one XCD each (image x, x + 8, ... on XCD x), the other R = N % 8 are cut into F = 8, 4, 2, 1 bands for R = 1, 2,
+    3..4, 5..7 with 8 / F of them in flight (csrc/march.hip).  N = 8: whole only; 5: F = 1 with idle XCDs; 10 (F = 4) and
+    17 (F = 8): both regimes in one grid; every image, ragged packets included, must match the oracle.  (The other tests
+    run N = 1..4: F = 8, 4, 2, 2.)"""
+    from ava256_amd.scene import make_scene
+    H, W, K = 44, 52, 150
+    s = make_scene(N, H, W, K, device="cpu", seed=70 + N, alpha_gain=3.0)
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    assert st["rays_hit"] > 0
+    gout = np.random.default_rng(N).normal(size=ref_rgba.shape)
+    fragile = FragileRays(ref_sat, st["margin"], gout)
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
+    fr = fragile.mask
+    err = np.abs(rgba - ref_rgba).max(-1)
+    assert (err[~fr] > FWD_TOL * max(1.0, np.abs(ref_rgba).max())).sum() == 0, err[~fr].max()
+    for n in range(N):   # no image may be skipped or rendered twice into another one's slot
+        assert np.abs(rgba[n]).max() > 0
+    rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, fragile.masked())
+    _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "N=%d %s" % (N, mode))
+
+
 def test_backward_twice_over_one_forward(ops):
     """retain_graph / several losses: the backward marks things in the forward's hand-off buffer (primitives it hands
     to the ray-centric kernel) and derives its fixed-point scales from the upstream gradient of THAT call.  A second
