@@ -1525,6 +1525,11 @@ constexpr int kEntriesPerWave = MVP_ENTRIES_PER_WAVE;  // list entries (packets)
 __host__ __device__ constexpr int prim_entries_per_round(int pw) { return pw * kEntriesPerWave; }  // typical lists: ONE round
 __host__ __device__ constexpr int prim_queue_cap(int pw) { return prim_entries_per_round(pw) * 64; }  // rays per round
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
+constexpr int kPrimGranule = 128;   // primitives per granule when F XCDs share an image (block -> primitive mapping)
+// block slots of one XCD's share of an image's K primitives: whole granules, ceil(granules / F) of them
+__host__ __device__ constexpr int prim_band_slots(int K, int F) {
+    return (((K + kPrimGranule - 1) / kPrimGranule + F - 1) / F) * kPrimGranule;
+}
 
 // Backward prologue.  (1) Per ray packet (8x8 pixels): max |grad_rayrgba| -> pmax[packet] as float bits (non-negative
 // floats order like uints; a NaN's pattern is larger than Inf's, so it is sticky).  The primitive-centric kernel
@@ -1621,8 +1626,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
     const int K = p.K;
     // XCD-aware (block b runs on XCD b % 8): XCD x owns ALL primitives of images x, x + 8, ... of the first N - N % 8
     // images -- an image's ray records, which ~7 of its primitives re-read, then live in one L2 instead of eight; the
-    // remaining R images are split over F = band_split XCDs each (contiguous ranges of k: neighbours on the shell share
-    // rays), 8 / F images at a time (see march_packet).
+    // remaining R images are split over F = band_split XCDs each, 8 / F images at a time (see march_packet).
     const int b = blockIdx.x, blocks_whole = p.images_whole * K;
     int n, k;
     if (b < blocks_whole) {
@@ -1630,8 +1634,11 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
         n = q * 8 + xcd, k = i - q * K;
     } else {
         const int bb = b - blocks_whole, xcd = bb & 7, i = bb >> 3;
-        const int F = p.band_split, chunkk = (K + F - 1) / F, q = i / chunkk;
-        n = p.images_whole + q * (8 / F) + xcd / F, k = (xcd % F) * chunkk + (i - q * chunkk);
+        // granules of kPrimGranule primitives (neighbours on the shell share rays) dealt cyclically to the F XCDs of an
+        // image; contiguous ranges of k were 4.5 % slower at C4, equal at C3
+        const int F = p.band_split, slots = prim_band_slots(K, F), q = i / slots, il = i - q * slots;
+        n = p.images_whole + q * (8 / F) + xcd / F;
+        k = ((il / kPrimGranule) * F + xcd % F) * kPrimGranule + il % kPrimGranule;
         if (n >= p.N || k >= K) return;
     }
     const size_t pk = (size_t)n * K + k;
@@ -2570,7 +2577,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         p.fallback_all = 1;
     } else {
         const long long pb = (long long)p.images_whole * K +
-                             8ll * ((K + p.band_split - 1) / p.band_split) * (((N - p.images_whole) * p.band_split + 7) / 8);
+                             8ll * prim_band_slots(K, p.band_split) * (((N - p.images_whole) * p.band_split + 7) / 8);
         if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
         // bounds for the fixed-point scales: per-packet max |grad_rayrgba| behind the tail of primlist_count (max |raysat|
         // is in the tail already, written by the forward); also clears what an earlier backward left behind
