@@ -3,8 +3,8 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-render"
 cp ava-256_amd/libmvp_gfx950.so /tmp/prod.so
-for v in cy16 cy128 prod; do
+for v in f48_20 f64_24 f64_32 prod; do
   if [ $v = prod ]; then cp /tmp/prod.so ava-256_amd/libmvp_gfx950.so; else cp build_variants/libmvp_$v.so ava-256_amd/libmvp_gfx950.so; fi
-  for w in C3 C4; do echo -n "$v $w: "; timeout 300 $B --workload $w 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.2f' % d['ms_per_step'], {k: round(v,3) for k,v in d['kernel_ms'].items()})"; done
+  for w in C2 C3; do echo -n "$v $w: "; timeout 300 $B --workload $w 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.2f' % d['ms_per_step'], {k: round(v,3) for k,v in d['kernel_ms'].items()})"; done
 done
 cp /tmp/prod.so ava-256_amd/libmvp_gfx950.so
