@@ -92,8 +92,8 @@ struct MarchParams {
     int prim_lds_base;    // bwd_prim_kernel<.., WARP>: byte offset of the warp-field arrays in its dynamic LDS
     int total_packets;    // blocks of the march grid: images_whole * 8 * chunk + 8 * chunk * (N - images_whole)
     int images_whole;     // the first N - N % 8 images: XCD x owns images x, x + 8, ... whole
-    int band_split;       // the other R = N % 8 images: each is cut into F = band_split bands (8, 4, 2, 1 for R = 1, 2, <= 4, > 4),
-    int band_chunk;       //   ceil(T / F) packets each; 8 / F images are in flight at a time, one XCD per band
+    int band_split;       // the other R = N % 8 images: F = band_split XCDs share each (2 for R = 4, 4 for R = 2, else 8),
+    int band_chunk;       //   packet slots of one XCD's share; 8 / F images are in flight at a time
     // Only read by builds with -DMVP_DEBUG_HOOKS (tools/exp_variants.sh); the product library ignores the environment.
     int debug_force_dfs;  // MVP_DEBUG_FORCE_DFS=1 makes every packet take the exact DFS traversal
     int debug_slot_sweep; // MVP_DEBUG_SLOT_SWEEP=1 makes every packet take the slot-synchronous forward sweep
@@ -508,7 +508,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     // blocks apart instead of a row apart).  F XCDs share an image by taking its strips cyclically, 8 / F images are in
     // flight at a time:
     //   * the first N - N % 8 images: F = 1, XCD x renders images x, x + 8, ... whole;
-    //   * the other R = N % 8 images (all of them when N < 8): F = 8, 4, 2, 1 for R = 1, 2, 3..4, 5..7.
+    //   * the other R = N % 8 images (all of them when N < 8): F = 2 for R = 4, 4 for R = 2, else 8.
     // Why: the first version gave XCD x the x-th horizontal BAND of every image -- the top and bottom bands of a head
     // shot are background, so two XCDs idled while the two middle ones carried the kernel (same total wave-cycles, 30 %
     // longer wall time).  C2 forward 7.51 ms (bands, row-major) -> 7.04 (bands, strips) -> 5.30 (whole images); C3 / C4
@@ -2397,7 +2397,9 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     p.chunk = (int)((strips * S + 7) / 8);            // 8 * chunk >= the slots of a whole image
     p.images_whole = p.N - p.N % 8;
     const int R = p.N - p.images_whole;
-    p.band_split = R == 0 ? 8 : R == 1 ? 8 : R == 2 ? 4 : R <= 4 ? 2 : 1;
+    // XCDs per shared image (measured, forward ms, F = 8 / 4 / 2 or 1): R = 4 (C3) 0.76 / 0.74 / 0.70, (C4) 1.00 / 0.98 /
+    // 0.97; R = 2: 0.36 / 0.36 / -; R = 5: 0.61 / 0.66 / 0.80 (F = 1: three XCDs idle)
+    p.band_split = R == 4 ? 2 : R == 2 ? 4 : 8;
     p.band_chunk = (int)(((strips + p.band_split - 1) / p.band_split) * S);  // slots of one XCD's share of an image
     const int rounds = (R * p.band_split + 7) / 8;  // groups of 8 / F images
     const long long blocks = 8ll * p.chunk * p.images_whole + 8ll * p.band_chunk * rounds;

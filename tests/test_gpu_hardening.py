@@ -181,10 +181,10 @@ def test_warp_field_backward_is_reproducible(ops):
 @pytest.mark.parametrize("N", [5, 8, 10, 17])
 def test_block_to_image_mapping_with_eight_or_more_images(ops, oracle64, N, mode):
     """Blocks are mapped to (image, packet) / (image, primitive) in two regimes: the first N - N % 8 images go whole to
-    one XCD each (image x, x + 8, ... on XCD x), the other R = N % 8 are cut into F = 8, 4, 2, 1 bands for R = 1, 2,
-    3..4, 5..7 with 8 / F of them in flight (csrc/march.hip).  N = 8: whole only; 5: F = 1 with idle XCDs; 10 (F = 4) and
-    17 (F = 8): both regimes in one grid; every image, ragged packets included, must match the oracle.  (The other tests
-    run N = 1..4: F = 8, 4, 2, 2.)"""
+    one XCD each (image x, x + 8, ... on XCD x), the other R = N % 8 are shared by F XCDs each (2 for R = 4, 4 for R = 2,
+    else 8) with 8 / F of them in flight (csrc/march.hip).  N = 8: whole only; 5: five shared images in five rounds;
+    10 (F = 4) and 17 (F = 8): both regimes in one grid; every image, ragged packets included, must match the oracle.
+    (The other tests run N = 1..4: F = 8, 4, 8, 2.)"""
     from ava256_amd.scene import make_scene
     H, W, K = 44, 52, 150
     s = make_scene(N, H, W, K, device="cpu", seed=70 + N, alpha_gain=3.0)
