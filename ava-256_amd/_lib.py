@@ -50,6 +50,8 @@ SIGNATURES["mvp_grads_clip_scale"] = (_c_int, [_c_int] + [_c_void_p] * 3 + [_c_f
 SIGNATURES["mvp_bgmlp_forward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 10 + [_c_void_p])
 # B, HW | grad_out, acts, whT, w6, dz, colsum | stream
 SIGNATURES["mvp_bgmlp_backward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 6 + [_c_void_p])
+# N, H, W, K, kind, first_block, count | out, total_blocks
+SIGNATURES["mvp_march_block_map"] = (_c_int, [_c_int] * 7 + [_c_void_p] * 2)
 ABI_VERSION = 9
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",

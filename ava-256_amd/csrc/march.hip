@@ -495,26 +495,26 @@ __device__ __forceinline__ bool lane_step_range(float tn, float tf, float tmin, 
     return lo <= hi;
 }
 
-template <bool BWD, bool FADE8, bool WARP, int TS>
-__device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
-                                             uint32_t *s_tab, const bool emit_all) {
-    constexpr bool FAST = !BWD && !WARP;  // the lane-independent sweep exists for the plain forward only
-    const int lane = lane_id();
-    const unsigned long long lt = lanemask_lt(lane);
+constexpr int kPrimGranule = 128;   // primitives per granule when F XCDs share an image (block -> primitive mapping)
+// block slots of one XCD's share of an image's K primitives: whole granules, ceil(granules / F) of them
+__host__ __device__ constexpr int prim_band_slots(int K, int F) {
+    return (((K + kPrimGranule - 1) / kPrimGranule + F - 1) / F) * kPrimGranule;
+}
 
-    // ---- packet -> (image, tile).  Block b runs on XCD b % 8 (MI355X_MICROARCH "Workgroup dispatch"), so the block
-    // index decides which XCD renders what, statically.  An image is a sequence of strips (MVP_STRIP_ROWS packet rows,
-    // walked column by column: the packets that share a primitive's slab -- it spans ~2 x 2 packets at C2 -- start a few
-    // blocks apart instead of a row apart).  F XCDs share an image by taking its strips cyclically, 8 / F images are in
-    // flight at a time:
-    //   * the first N - N % 8 images: F = 1, XCD x renders images x, x + 8, ... whole;
-    //   * the other R = N % 8 images (all of them when N < 8): F = 2 for R = 4, 4 for R = 2, else 8.
-    // Why: the first version gave XCD x the x-th horizontal BAND of every image -- the top and bottom bands of a head
-    // shot are background, so two XCDs idled while the two middle ones carried the kernel (same total wave-cycles, 30 %
-    // longer wall time).  C2 forward 7.51 ms (bands, row-major) -> 7.04 (bands, strips) -> 5.30 (whole images); C3 / C4
-    // (N = 4) 0.81 / 1.12 -> 0.70 / 0.93 with two half-image bands per image -> see DESIGN.md 3.3 for the cyclic form.
+// ---- packet -> (image, tile).  Block b runs on XCD b % 8 (MI355X_MICROARCH "Workgroup dispatch"), so the block
+// index decides which XCD renders what, statically.  An image is a sequence of strips (MVP_STRIP_ROWS packet rows,
+// walked column by column: the packets that share a primitive's slab -- it spans ~2 x 2 packets at C2 -- start a few
+// blocks apart instead of a row apart).  F XCDs share an image by taking its strips cyclically, 8 / F images are in
+// flight at a time:
+//   * the first N - N % 8 images: F = 1, XCD x renders images x, x + 8, ... whole;
+//   * the other R = N % 8 images (all of them when N < 8): F = 2 for R = 4, 4 for R = 2, else 8.
+// Why: the first version gave XCD x the x-th horizontal BAND of every image -- the top and bottom bands of a head
+// shot are background, so two XCDs idled while the two middle ones carried the kernel (same total wave-cycles, 30 %
+// longer wall time).  C2 forward 7.51 ms (bands, row-major) -> 7.04 (bands, strips) -> 5.30 (whole images); C3 / C4
+// (N = 4) 0.81 / 1.12 -> 0.70 / 0.93 with two half-image bands per image -> see DESIGN.md 3.3 for the cyclic form.
+__host__ __device__ inline bool packet_of_block(const MarchParams &p, int b, int &n, int &tidx) {
     const int T8 = 8 * p.chunk, blocks_whole = p.images_whole * T8;
-    int n, j, F, band;  // image, packet slot inside this XCD's share of the image, XCDs per image, which of them
+    int j, F, band;  // packet slot inside this XCD's share of the image, XCDs per image, which of them
     if (b < blocks_whole) {
         const int xcd = b & 7, i = b >> 3, q = i / T8;
         n = q * 8 + xcd, j = i - q * T8, F = 1, band = 0;
@@ -522,20 +522,49 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         const int bb = b - blocks_whole, xcd = bb & 7, i = bb >> 3, q = i / p.band_chunk;
         F = p.band_split, band = xcd % F;
         n = p.images_whole + q * (8 / F) + xcd / F, j = i - q * p.band_chunk;
-        if (n >= p.N) return;
+        if (n >= p.N) return false;
     }
-    int tidx;
-    {
-        const int S = MVP_STRIP_ROWS * p.tiles_x;          // packet slots per strip
-        const int strip = (j / S) * F + band, jj = j % S;  // the strip of the image, the slot inside it
-        const int row0 = strip * MVP_STRIP_ROWS, rows = min(MVP_STRIP_ROWS, p.tiles_y - row0);
-        if (rows <= 0 || jj >= rows * p.tiles_x) return;   // (a ragged last strip leaves some slots empty)
+    const int S = MVP_STRIP_ROWS * p.tiles_x;          // packet slots per strip
+    const int strip = (j / S) * F + band, jj = j % S;  // the strip of the image, the slot inside it
+    const int row0 = strip * MVP_STRIP_ROWS;
+    const int rows = p.tiles_y - row0 < MVP_STRIP_ROWS ? p.tiles_y - row0 : MVP_STRIP_ROWS;
+    if (rows <= 0 || jj >= rows * p.tiles_x) return false;  // (a ragged last strip leaves some slots empty)
 #ifndef MVP_NO_STRIP_ORDER
-        tidx = (row0 + jj % rows) * p.tiles_x + jj / rows;
+    tidx = (row0 + jj % rows) * p.tiles_x + jj / rows;
 #else
-        tidx = row0 * p.tiles_x + jj;
+    tidx = row0 * p.tiles_x + jj;
 #endif
+    return true;
+}
+
+// Block -> (image, primitive) of the primitive-centric backward (block b runs on XCD b % 8): XCD x owns ALL primitives of
+// images x, x + 8, ... of the first N - N % 8 images -- an image's ray records, which ~7 of its primitives re-read, then
+// live in one L2 instead of eight; the remaining R images are split over F = band_split XCDs each, 8 / F images at a
+// time (see packet_of_block), in granules of kPrimGranule primitives (neighbours on the shell share rays) dealt
+// cyclically; contiguous ranges of k were 4.5 % slower at C4, equal at C3.
+__host__ __device__ inline bool prim_of_block(const MarchParams &p, int b, int &n, int &k) {
+    const int K = p.K, blocks_whole = p.images_whole * K;
+    if (b < blocks_whole) {
+        const int xcd = b & 7, i = b >> 3, q = i / K;
+        n = q * 8 + xcd, k = i - q * K;
+        return true;
     }
+    const int bb = b - blocks_whole, xcd = bb & 7, i = bb >> 3;
+    const int F = p.band_split, slots = prim_band_slots(K, F), q = i / slots, il = i - q * slots;
+    n = p.images_whole + q * (8 / F) + xcd / F;
+    k = ((il / kPrimGranule) * F + xcd % F) * kPrimGranule + il % kPrimGranule;
+    return n < p.N && k < K;
+}
+
+template <bool BWD, bool FADE8, bool WARP, int TS>
+__device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
+                                             uint32_t *s_tab, const bool emit_all) {
+    constexpr bool FAST = !BWD && !WARP;  // the lane-independent sweep exists for the plain forward only
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt(lane);
+
+    int n, tidx;
+    if (!packet_of_block(p, b, n, tidx)) return;
     const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
     const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
     const bool inimg = px < p.W && py < p.H;
@@ -1525,11 +1554,6 @@ constexpr int kEntriesPerWave = MVP_ENTRIES_PER_WAVE;  // list entries (packets)
 __host__ __device__ constexpr int prim_entries_per_round(int pw) { return pw * kEntriesPerWave; }  // typical lists: ONE round
 __host__ __device__ constexpr int prim_queue_cap(int pw) { return prim_entries_per_round(pw) * 64; }  // rays per round
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
-constexpr int kPrimGranule = 128;   // primitives per granule when F XCDs share an image (block -> primitive mapping)
-// block slots of one XCD's share of an image's K primitives: whole granules, ceil(granules / F) of them
-__host__ __device__ constexpr int prim_band_slots(int K, int F) {
-    return (((K + kPrimGranule - 1) / kPrimGranule + F - 1) / F) * kPrimGranule;
-}
 
 // Backward prologue.  (1) Per ray packet (8x8 pixels): max |grad_rayrgba| -> pmax[packet] as float bits (non-negative
 // floats order like uints; a NaN's pattern is larger than Inf's, so it is sticky).  The primitive-centric kernel
@@ -1624,23 +1648,8 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int K = p.K;
-    // XCD-aware (block b runs on XCD b % 8): XCD x owns ALL primitives of images x, x + 8, ... of the first N - N % 8
-    // images -- an image's ray records, which ~7 of its primitives re-read, then live in one L2 instead of eight; the
-    // remaining R images are split over F = band_split XCDs each, 8 / F images at a time (see march_packet).
-    const int b = blockIdx.x, blocks_whole = p.images_whole * K;
     int n, k;
-    if (b < blocks_whole) {
-        const int xcd = b & 7, i = b >> 3, q = i / K;
-        n = q * 8 + xcd, k = i - q * K;
-    } else {
-        const int bb = b - blocks_whole, xcd = bb & 7, i = bb >> 3;
-        // granules of kPrimGranule primitives (neighbours on the shell share rays) dealt cyclically to the F XCDs of an
-        // image; contiguous ranges of k were 4.5 % slower at C4, equal at C3
-        const int F = p.band_split, slots = prim_band_slots(K, F), q = i / slots, il = i - q * slots;
-        n = p.images_whole + q * (8 / F) + xcd / F;
-        k = ((il / kPrimGranule) * F + xcd % F) * kPrimGranule + il % kPrimGranule;
-        if (n >= p.N || k >= K) return;
-    }
+    if (!prim_of_block(p, blockIdx.x, n, k)) return;
     const size_t pk = (size_t)n * K + k;
     uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] reserved, [2] bits(Rmax); then per-packet bits(max |g|)
     const uint32_t *pmax_n = tail + 3 + (size_t)n * p.tiles_x * p.tiles_y;
@@ -2367,6 +2376,55 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
 }  // namespace mvp
 
 // ------------------------------------------------------------------------------------------------
+// Grid geometry of the march kernels from (N, H, W, K): fills the fields packet_of_block / prim_of_block read.
+static int setup_block_map(mvp::MarchParams &p) {
+    using namespace mvp;
+    p.tiles_x = (p.W + kTile - 1) / kTile;
+    p.tiles_y = (p.H + kTile - 1) / kTile;
+    // packet slots: an image is ceil(tiles_y / MVP_STRIP_ROWS) strips of MVP_STRIP_ROWS * tiles_x slots (packet_of_block)
+    const long long strips = (p.tiles_y + MVP_STRIP_ROWS - 1) / MVP_STRIP_ROWS, S = (long long)MVP_STRIP_ROWS * p.tiles_x;
+    if (strips * S > 0x3fffffffll) return MVP_ERR_UNSUPPORTED;
+    p.chunk = (int)((strips * S + 7) / 8);            // 8 * chunk >= the slots of a whole image
+    p.images_whole = p.N - p.N % 8;
+    const int R = p.N - p.images_whole;
+    // XCDs per shared image (measured, forward ms, F = 8 / 4 / 2 or 1): R = 4 (C3) 0.76 / 0.74 / 0.70, (C4) 1.00 / 0.98 /
+    // 0.97; R = 2: 0.36 / 0.36 / -; R = 5: 0.61 / 0.66 / 0.80 (F = 1: three XCDs idle)
+    p.band_split = R == 4 ? 2 : R == 2 ? 4 : 8;
+    p.band_chunk = (int)(((strips + p.band_split - 1) / p.band_split) * S);  // slots of one XCD's share of an image
+    const int rounds = (R * p.band_split + 7) / 8;  // groups of 8 / F images
+    const long long blocks = 8ll * p.chunk * p.images_whole + 8ll * p.band_chunk * rounds;
+    if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
+    p.total_packets = (int)blocks;
+    return MVP_OK;
+}
+
+// blocks of the primitive-centric backward's grid
+static long long prim_grid_blocks(const mvp::MarchParams &p) {
+    return (long long)p.images_whole * p.K +
+           8ll * mvp::prim_band_slots(p.K, p.band_split) * (((p.N - p.images_whole) * p.band_split + 7) / 8);
+}
+
+extern "C" int mvp_march_block_map(int N, int H, int W, int K, int kind, int first_block, int count, int *out,
+                                   int *total_blocks) {
+    using namespace mvp;
+    if (N < 0 || H < 0 || W < 0 || K < 0 || (kind != 0 && kind != 1) || first_block < 0 || count < 0) return MVP_ERR_BADARG;
+    if (count > 0 && !out) return MVP_ERR_BADARG;
+    MarchParams p = {};
+    p.N = N, p.H = H, p.W = W, p.K = K;
+    const int rc = setup_block_map(p);
+    if (rc != MVP_OK) return rc;
+    const long long total = kind == 0 ? (long long)p.total_packets : prim_grid_blocks(p);
+    if (total > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
+    if (total_blocks) *total_blocks = (int)total;
+    for (int i = 0; i < count; ++i) {
+        const long long b = (long long)first_block + i;
+        int n = -1, u = -1;
+        const bool ok = b < total && (kind == 0 ? packet_of_block(p, (int)b, n, u) : prim_of_block(p, (int)b, n, u));
+        out[2 * i] = ok ? n : -1, out[2 * i + 1] = ok ? u : -1;
+    }
+    return MVP_OK;
+}
+
 static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     using namespace mvp;
     if (p.N < 0 || p.H < 0 || p.W < 0 || p.K < 0) return MVP_ERR_BADARG;
@@ -2388,23 +2446,8 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     if (p.pl_cap < 0) return MVP_ERR_BADARG;
     if (p.rayaux && !aligned16(p.rayaux)) return MVP_ERR_BADARG;
     if (p.pl_list && !aligned16(p.pl_list)) return MVP_ERR_BADARG;
-    p.tiles_x = (p.W + kTile - 1) / kTile;
-    p.tiles_y = (p.H + kTile - 1) / kTile;
-    const long long T = (long long)p.tiles_x * p.tiles_y;
-    // packet slots: an image is ceil(tiles_y / MVP_STRIP_ROWS) strips of MVP_STRIP_ROWS * tiles_x slots (march_packet)
-    const long long strips = (p.tiles_y + MVP_STRIP_ROWS - 1) / MVP_STRIP_ROWS, S = (long long)MVP_STRIP_ROWS * p.tiles_x;
-    if (strips * S > 0x3fffffffll) return MVP_ERR_UNSUPPORTED;
-    p.chunk = (int)((strips * S + 7) / 8);            // 8 * chunk >= the slots of a whole image
-    p.images_whole = p.N - p.N % 8;
-    const int R = p.N - p.images_whole;
-    // XCDs per shared image (measured, forward ms, F = 8 / 4 / 2 or 1): R = 4 (C3) 0.76 / 0.74 / 0.70, (C4) 1.00 / 0.98 /
-    // 0.97; R = 2: 0.36 / 0.36 / -; R = 5: 0.61 / 0.66 / 0.80 (F = 1: three XCDs idle)
-    p.band_split = R == 4 ? 2 : R == 2 ? 4 : 8;
-    p.band_chunk = (int)(((strips + p.band_split - 1) / p.band_split) * S);  // slots of one XCD's share of an image
-    const int rounds = (R * p.band_split + 7) / 8;  // groups of 8 / F images
-    const long long blocks = 8ll * p.chunk * p.images_whole + 8ll * p.band_chunk * rounds;
-    if (blocks > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
-    p.total_packets = (int)blocks;
+    const int rc_grid = setup_block_map(p);
+    if (rc_grid != MVP_OK) return rc_grid;
 #ifdef MVP_DEBUG_HOOKS
     {
         const char *e = getenv("MVP_DEBUG_FORCE_DFS");
@@ -2578,8 +2621,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         if (norays) return MVP_OK;
         p.fallback_all = 1;
     } else {
-        const long long pb = (long long)p.images_whole * K +
-                             8ll * prim_band_slots(K, p.band_split) * (((N - p.images_whole) * p.band_split + 7) / 8);
+        const long long pb = prim_grid_blocks(p);
         if (pb > 0x7fffffffll) return MVP_ERR_UNSUPPORTED;
         // bounds for the fixed-point scales: per-packet max |grad_rayrgba| behind the tail of primlist_count (max |raysat|
         // is in the tail already, written by the forward); also clears what an earlier backward left behind

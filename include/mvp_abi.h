@@ -127,6 +127,14 @@ int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const fl
                        float *grad_tplate, float *grad_warp /*NULL iff warp is NULL*/, float fadescale,
                        float fadeexp, uint32_t *diag, void *stream);
 
+/* Which thread block of the march grids does what -- a host-side evaluation of the same functions the kernels use
+ * (tests and tools; no device work).  The grids are XCD-aware: block b runs on XCD b % 8, whole images go to single XCDs
+ * and the rest are shared.  kind 0: forward / ray-centric grid, out[i] = {image, 8x8 packet index};
+ * kind 1: primitive-centric backward grid, out[i] = {image, primitive}; {-1, -1} for a block with nothing to do.
+ * `count` entries from block `first_block` on are written; *total_blocks (may be NULL) receives the grid size. */
+int mvp_march_block_map(int N, int H, int W, int K, int kind, int first_block, int count, int *out /*[count][2]*/,
+                        int *total_blocks);
+
 /* Decoder -> raymarch hand-off (no counterpart in the reference's extensions: there it is eager PyTorch spread over
  * models/decoders/rgb.py:137-143, models/decoders/geometry.py:183-185 and models/decoders/assembler.py:261).
  *   tex     [N, 3*B, nh*B, nh*B]  RGB decoder output (conv output + bias), channel index = z*3 + c
