@@ -324,7 +324,11 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                  "C2": train_leg("C2", 6, 2, rank, local_rank, world, dev, dist, with_bg=False)}
         # the 80-frame batch WITH the background MLP: its bf16 activations and their gradients for the backward are
         # 2 x 54 GB (80 x 512 x 512 pixels x 5 layers x 256 channels) -- run when the device has the room
-        if torch.cuda.mem_get_info(dev)[0] > 160 * (1 << 30):
+        # (the decision is taken by ALL ranks together -- a rank that skipped the leg would leave the others in its barrier)
+        free = torch.tensor([float(torch.cuda.mem_get_info(dev)[0])], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(free, op=dist.ReduceOp.MIN)
+        if float(free.item()) > 160 * (1 << 30):
             train["C2_bg"] = train_leg("C2", 3, 1, rank, local_rank, world, dev, dist, with_bg=True)
 
     if rank == 0:
