@@ -30,8 +30,9 @@
 //     and the alpha just before (rayaux), so samples can be regrouped by primitive.  The forward appends every
 //     (packet, list slot, step range) to a per-primitive list; one workgroup per primitive then stages that
 //     primitive's slab in LDS, re-evaluates its samples ray packet by ray packet, accumulates the slab gradient
-//     with LDS float atomics (ds_add_f32) and writes it back ONCE with coalesced 16-byte stores -- no global
-//     atomics, no zero-fill pass.  The ray-centric backward with global_atomic_add_f32 (march_kernel<true,*>)
+//     in FIXED POINT with LDS integer atomics (ds_add_u32; ds_add_f32 retires ~3 cycles per active lane on gfx950,
+//     see bwd_prim_kernel) and writes it back ONCE with coalesced 16-byte stores -- no global atomics, no zero-fill
+//     pass.  The ray-centric backward with global_atomic_add_f32 (march_kernel<true,*>)
 //     is kept as the always-correct fallback for primitives whose list overflowed (device-side flag).
 #include <stdlib.h>
 

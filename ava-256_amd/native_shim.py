@@ -17,10 +17,11 @@ What the shims do with arguments the gfx950 kernels have no use for:
                                           ignored like the reference's kernels ignore them (hard-wired template
                                           arguments, mvpraymarch_kernel.cu:33,101-102,188-189)
   chlast = False                          rejected (the reference's sampler is instantiated channels-last only)
-The forward keeps the hand-off buffers of the primitive-centric backward (rayaux, packet lists) in a small cache keyed
-by the `rayrgba` tensor the reference's autograd Function saves and passes back, so the backward runs the fast path.
+The forward keeps the hand-off buffers of the primitive-centric backward (rayaux, packet lists) attached to the STORAGE
+of the `rayrgba` tensor the reference's autograd Function saves and passes back (the saved tensor is unpacked as a new
+tensor object over the same storage), so the backward runs the fast path; the entry dies with that storage.
 """
-import collections
+import weakref
 
 import torch
 
@@ -28,8 +29,40 @@ from . import _hooks, _lib
 from ._tensors import aligned, ptr, require_device_f32, stream_ptr
 from .mvpraymarch import primlist_capacity
 
-_HANDOFF = collections.OrderedDict()  # rayrgba.data_ptr() -> (rayaux, pl_count, pl_list, pl_cap)
-_HANDOFF_MAX = 8
+# rayrgba.data_ptr() -> ((N, H, W, K), rayaux, pl_count, pl_list, pl_cap).  An entry lives exactly as long as the
+# rayrgba STORAGE: a finaliser on the storage object removes it (a forward whose backward never runs leaks nothing, and
+# the caching allocator cannot hand the address to another tensor while the entry exists).
+_HANDOFF = {}
+
+
+def _handoff_put(rayrgba, shape, buffers):
+    key = rayrgba.data_ptr()
+    _HANDOFF[key] = (shape,) + tuple(buffers)
+    weakref.finalize(rayrgba.untyped_storage(), _HANDOFF.pop, key, None)
+
+
+def _handoff_take(rayrgba, shape):
+    """The buffers of the grad-mode forward that wrote `rayrgba`, or Nones (-> ray-centric backward) when there was
+    none or its geometry is not this call's.  Left in place: a second backward over the same forward (retain_graph)
+    finds them again; the storage's finaliser removes them."""
+    ent = _HANDOFF.get(rayrgba.data_ptr())
+    if ent is None or ent[0] != shape:
+        return None, None, None, 0
+    return ent[1:]
+
+
+def _identity_order(sortedobjid, K):
+    """usebvh='fixedorder' hands arange(K) per image (mvpraymarch.py:45); any other order (randomorder=True, the LBVH
+    path) would silently render in the wrong composition order here."""
+    if sortedobjid is None:
+        return
+    hit = getattr(sortedobjid, "_mvp_identity", None)
+    if hit != sortedobjid._version:
+        ar = torch.arange(K, device=sortedobjid.device, dtype=sortedobjid.dtype)
+        if sortedobjid.dim() != 2 or sortedobjid.size(1) != K or not bool((sortedobjid == ar[None]).all()):
+            raise NotImplementedError("sortedobjid is not the fixed identity order: only usebvh='fixedorder' without "
+                                      "randomorder is supported")
+        sortedobjid._mvp_identity = sortedobjid._version
 
 
 def compute_morton(*args):
@@ -72,17 +105,22 @@ def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildre
     if algo == 0:
         warp = None
     WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
+    _identity_order(sortedobjid, K)
     raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
+    if warp is not None:
+        warp = aligned(require_device_f32("warp", warp))
+    require_device_f32("rayrgba", rayrgba)
+    if rayrgba.data_ptr() & 15:
+        raise RuntimeError("rayrgba must be 16-byte aligned")
     rayaux = pl_count = pl_list = None
     pl_cap = 0
     if raysat is not None:
+        require_device_f32("raysat", raysat)
         pl_cap = primlist_capacity(H, W, K)
         rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
         pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
         pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
-        _HANDOFF[rayrgba.data_ptr()] = (rayaux, pl_count, pl_list, pl_cap)
-        while len(_HANDOFF) > _HANDOFF_MAX:
-            _HANDOFF.popitem(last=False)
+        _handoff_put(rayrgba, (N, H, W, K), (rayaux, pl_count, pl_list, pl_cap))
     with torch.cuda.device(dev):
         _lib.check(_lib.get_lib().mvp_march_forward(
             N, H, W, K, ptr(raypos), ptr(raydir), float(stepsize), ptr(tminmax), ptr(nodeaabb), ptr(primpos),
@@ -100,14 +138,28 @@ def raymarch_backward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildr
     pre-fills them with, mvpraymarch.py:240-246, are not needed)."""
     if not chlast:
         raise NotImplementedError("channels-first templates: the reference instantiates only the channels-last sampler")
+    if algo not in (0, 1):
+        raise NotImplementedError("algo must be 0 or 1")
+    # the same checks and 16-byte treatment as the forward (an offset view must not pass one and fail the other)
+    for n, t in (("raypos", raypos), ("raydir", raydir), ("tminmax", tminmax), ("nodeaabb", nodeaabb),
+                 ("primpos", primpos), ("primrot", primrot), ("primscale", primscale), ("template", template),
+                 ("raysat", raysat), ("grad_primpos", grad_primpos), ("grad_primrot", grad_primrot),
+                 ("grad_primscale", grad_primscale), ("grad_template", grad_template)):
+        require_device_f32(n, t)
     N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
     K = primpos.size(1)
     TD, TH, TW = template.size(2), template.size(3), template.size(4)
     dev = raypos.device
+    _identity_order(sortedobjid, K)
     if algo == 0:
         warp = grad_warp = None
     WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
-    rayaux, pl_count, pl_list, pl_cap = _HANDOFF.pop(rayrgba.data_ptr(), (None, None, None, 0))
+    raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
+    if warp is not None:
+        warp = aligned(require_device_f32("warp", warp))
+    if grad_template.data_ptr() & 15:
+        raise RuntimeError("grad_template must be 16-byte aligned")  # an output: cannot be replaced by a copy
+    rayaux, pl_count, pl_list, pl_cap = _handoff_take(rayrgba, (N, H, W, K))
     grad_rayrgba = aligned(require_device_f32("grad_rayrgba", grad_rayrgba))
     with torch.cuda.device(dev):
         _lib.check(_lib.get_lib().mvp_march_backward(
@@ -121,6 +173,8 @@ def raymarch_backward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildr
 def compute_raydirs_forward(viewpos, viewrot, focal, princpt, pixelcoords, W, H, volradius, raypos, raydir, tminmax):
     """utils.cpp:46-64 -> mvp_raydirs_forward (pixelcoords may be None: integer pixel grid)."""
     for n, t in (("viewpos", viewpos), ("viewrot", viewrot), ("focal", focal), ("princpt", princpt)):
+        require_device_f32(n, t)
+    for n, t in (("raypos", raypos), ("raydir", raydir), ("tminmax", tminmax)):
         require_device_f32(n, t)
     N = viewpos.size(0)
     dev = viewpos.device

@@ -7,8 +7,9 @@ autoencoder calls:  compute_raydirs -> (AABB build + march forward, grad mode) -
 timed region.  Workload at N=1 (and per GPU for N>1, weak scaling): BASELINE.json configs[1] =
 "C2": 1 subject, 80 cameras, 512x512, K=4096 primitives, 8^3 RGBA slabs, fp32.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run
-(one rank per GPU, RCCL); rank 0 prints ONE JSON line.  Every rank renders its own 80-camera scene (weak
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 either launched by torch.distributed.run
+(one rank per GPU, RCCL) or, when no launcher set WORLD_SIZE, starting its own N ranks (`self_launch`); rank 0
+prints ONE JSON line.  Every rank renders its own 80-camera scene (weak
 scaling; `--scaling strong` shards ONE scene's cameras over the ranks instead); there is no data-path
 collective (render/march units are independent: SURVEY.md section 8e) -- the only collectives of the march
 leg are the barriers and the MAX-reduce of the elapsed time.
@@ -235,6 +236,28 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
     return out
 
 
+def _spawned_rank(rank, world, port, argv, backend, make_step, device):
+    """Entry point of one self-launched rank (see self_launch): the environment torch.distributed.run would have set."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    main(argv, backend=backend, make_step=make_step, device=device)
+
+
+def self_launch(argv, world, backend, make_step, device):
+    """`python bench.py --gpus N` without a launcher: spawn one process per GPU on this node (rendezvous on 127.0.0.1,
+    a free port), like the reference's own `mp.spawn(run, nprocs=world_size)` (ddp-train.py:612-625).  Every rank then
+    runs main() exactly as under `python -m torch.distributed.run`; rank 0 prints the one JSON line to the inherited
+    stdout.  `make_step` (tests) must be a module-level function: the ranks are started with the spawn method."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    sys.stdout.flush()
+    mp.spawn(_spawned_rank, args=(world, port, argv, backend, make_step, device), nprocs=world, join=True)
+
+
 def main(argv=None, backend="nccl", make_step=None, device=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,9 +277,12 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                          "the headline value (iterations/s)")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks here, as the reference starts its own (ddp-train.py:612-625)
+        return self_launch(list(sys.argv[1:] if argv is None else argv), args.gpus, backend, make_step, device)
     rank, local_rank, world = env_ranks()
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE=%d)" % (args.gpus, world, world))
     gpu = device is None
     if gpu:
         assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
@@ -360,11 +386,15 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             dom_bytes = bb if dom == "march_backward" else bf
             dom_ms = kavg.get(dom, float("nan"))
             achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from rocprofv3 PMC passes
+            # per-launch HBM bytes from separate rocprofv3 PMC passes (tools/make_traffic.py): a RECORDED measurement,
+            # stamped with the commit it was taken at -- this run did not collect counters
+            traffic = traffic_at = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                    doc = json.load(open(tf))
+                    traffic = doc.get(args.workload, {}).get(dom)
+                    traffic_at = doc.get("_measured_at_commit")
                 except Exception:
                     traffic = None
             out["fwd_rays_per_s"] = (info["n_local"] * H * W) / (kavg["march_forward"] * 1e-3) if "march_forward" in kavg else None
@@ -374,6 +404,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                                  "ms": render_ms, "rays_per_s": info["n_local"] * H * W / (render_ms * 1e-3)}
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_measured_at_commit": traffic_at,
                                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                                "fwd": {"achieved": bf / (kavg.get("march_forward", float("nan")) * 1e-3) / 1e9,
                                        "algorithmic_bytes_per_launch": bf,

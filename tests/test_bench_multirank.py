@@ -89,3 +89,21 @@ def test_bench_two_ranks_strong_scaling(tmp_path):
     assert [shard_range(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]     # uneven shards are counted exactly:
     rays = 5 * 16 * 16                                                     # 5 cameras in total, not 2 x ceil(5/2)
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - rays) <= 1e-6 * rays
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path, monkeypatch, capfd):
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (the reference starts its ranks itself,
+    ddp-train.py:612-625): main() spawns the two ranks, and exactly one JSON line with n_gpus == 2 comes out."""
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("OMP_NUM_THREADS", "2")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    import bench
+    capfd.readouterr()
+    bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C1", "--cams", "3"], backend="gloo",
+               make_step=_oracle_step_factory, device="cpu")
+    lines = [l for l in capfd.readouterr().out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 2 * 3 * 16 * 16) <= 1e-6 * 2 * 3 * 16 * 16
