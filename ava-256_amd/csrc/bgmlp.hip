@@ -256,13 +256,18 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
             x0 = sc.x, x1 = sc.y;
         }
         __bf16 *row = X + r * kLdX + half * 20;
-        // v_sin_f32 / v_cos_f32 take their argument in revolutions and reduce it exactly (|arg| <= 256 here):
-        // sin(2^i pi x) = v_sin(2^(i-1) x).  Absolute error ~1e-6, far below the bf16 rounding of the result.
+        // v_sin_f32 / v_cos_f32 take their argument in revolutions: sin(2^i pi x) = v_sin(2^(i-1) x).  Their valid
+        // domain is |arg| <= 256 revolutions (outside it the hardware returns sin = 0, cos = 1), which 2^8 x leaves as
+        // soon as |x| > 1 -- cropped, sub-sampled or jittered pixelcoords under the shape-based normalisation of
+        // autoencoder.py:231-237 -- so the argument is reduced first: v_fract_f32 is exact and 2^(i-1) x is an exact
+        // product, hence sin(2 pi fract(r)) == sin(2 pi r) for every finite x (torch.sin/cos have no such limit
+        // either).  Absolute error ~1e-6, far below the bf16 rounding of the result.
         float f = 0.5f;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            row[2 * i] = (__bf16)(half ? __builtin_amdgcn_cosf(f * x0) : __builtin_amdgcn_sinf(f * x0));
-            row[2 * i + 1] = (__bf16)(half ? __builtin_amdgcn_cosf(f * x1) : __builtin_amdgcn_sinf(f * x1));
+            const float r0 = __builtin_amdgcn_fractf(f * x0), r1 = __builtin_amdgcn_fractf(f * x1);
+            row[2 * i] = (__bf16)(half ? __builtin_amdgcn_cosf(r0) : __builtin_amdgcn_sinf(r0));
+            row[2 * i + 1] = (__bf16)(half ? __builtin_amdgcn_cosf(r1) : __builtin_amdgcn_sinf(r1));
             f *= 2.f;
         }
         if (half) {

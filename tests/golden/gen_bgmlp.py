@@ -38,6 +38,27 @@ def main():
     np.savez_compressed(os.path.join(HERE, "bgmlp.npz"), **out)
     print("bgmlp.npz:", {k: v.shape for k, v in out.items() if not k.startswith("param/mlp")})
 
+    # Second fixture, SAME module (parameters are those of bgmlp.npz and are not stored again): two 64 x 64 images =
+    # 2 x 16 tiles of the fused kernels' 256 pixels, the second image with sample coordinates in [-2.5, 2.5] (cropped /
+    # jittered pixelcoords under autoencoder.py:231-237).  Gradients of the large square layers are kept for two of the
+    # four (1 MB less), every other gradient in full.
+    m.zero_grad()
+    g2 = torch.Generator().manual_seed(6)
+    B, H, W = 2, 64, 64
+    camindex, idindex = torch.tensor([1, 2]), torch.tensor([0, 1])
+    samplecoords = torch.rand(B, H, W, 2, generator=g2) * 2 - 1
+    samplecoords[1] *= 2.5
+    gout = torch.randn(B, 3, H, W, generator=g2)
+    bg = m(camindex, idindex, samplecoords)
+    (bg * gout).sum().backward()
+    out2 = dict(camindex=camindex.numpy(), idindex=idindex.numpy(), samplecoords=samplecoords.numpy(), gout=gout.numpy(),
+                bg=bg.detach().numpy())
+    for k, p in m.named_parameters():
+        if k not in ("mlp.4.weight", "mlp.8.weight"):
+            out2["grad/" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "bgmlp_multitile.npz"), **out2)
+    print("bgmlp_multitile.npz:", {k: v.shape for k, v in out2.items() if not k.startswith("grad/mlp")})
+
 
 if __name__ == "__main__":
     main()

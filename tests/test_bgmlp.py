@@ -10,15 +10,32 @@ import torch
 from conftest import ROOT
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "bgmlp.npz")
+# the same module (parameters of bgmlp.npz) on 2 x 64 x 64 pixels = 2 x 16 tiles of the fused kernels, the second image
+# with sample coordinates in [-2.5, 2.5]; tests/golden/gen_bgmlp.py
+GOLDEN_MULTITILE = os.path.join(ROOT, "tests", "golden", "bgmlp_multitile.npz")
 
 
-def _load(device, fused=True):
+class _Both:
+    """Inputs / expected values of one fixture, parameters always from bgmlp.npz."""
+
+    def __init__(self, params, data):
+        self.params, self.data = params, data
+        self.files = list(params.files) + list(data.files)
+
+    def __getitem__(self, k):
+        return self.params[k] if k.startswith("param/") else self.data[k]
+
+    def has(self, k):
+        return k in self.data.files
+
+
+def _load(device, fused=True, fixture=GOLDEN):
     import __graft_entry__  # noqa: F401
     from ava256_amd.trainloop import BackgroundMLPStandIn
-    g = np.load(GOLDEN)
+    g = _Both(np.load(GOLDEN), np.load(fixture))
     m = BackgroundMLPStandIn(3, 2, fused=fused)
     sd = {}
-    for k in g.files:
+    for k in g.params.files:
         if k.startswith("param/") and "ident" not in k:
             v = torch.from_numpy(g[k])
             sd[k[6:]] = v.reshape(v.shape[0], v.shape[1]) if v.dim() == 4 else v    # 1x1 Conv2d -> Linear
@@ -41,13 +58,24 @@ def _cos(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
 
 
-def test_standin_matches_the_reference_module_on_cpu():
-    m, g = _load("cpu")
+@pytest.mark.parametrize("fixture", [GOLDEN, GOLDEN_MULTITILE])
+def test_standin_matches_the_reference_module_on_cpu(fixture):
+    m, g = _load("cpu", fixture=fixture)
     bg, grads = _run(m, g, "cpu")
     assert np.abs(bg - g["bg"]).max() <= 1e-4 * np.abs(g["bg"]).max()
     for k, v in grads.items():
+        if not g.has("grad/" + k):
+            continue
         ref = g["grad/" + k].reshape(v.shape)
-        assert np.abs(v - ref).max() <= 1e-4 * np.abs(ref).max(), k
+        # float32 on both sides, Conv2d (reference) against Linear (stand-in): the summation order differs, and over the
+        # 2 M hidden units of the multi-tile fixture a couple of pre-activations within an ulp of zero take the other
+        # LeakyReLU slope -- one pixel's whole term in one row of an earlier layer's weight gradient.  ONE such flip is
+        # 0.8 / (sqrt(8192) * 16) = 5.5e-4 of a gradient's norm, and that is what is measured here (5-7e-4 on every
+        # gradient upstream of the second activation, 1e-6 downstream of it; 3e-3 of the largest element).  Element-wise
+        # bound on the small fixture, norm-wise (room for ~10 flips) on the large one.
+        if fixture == GOLDEN:
+            assert np.abs(v - ref).max() <= 1e-4 * np.abs(ref).max(), k
+        assert np.linalg.norm(v - ref) <= 2e-3 * np.linalg.norm(ref), (k, np.linalg.norm(v - ref) / np.linalg.norm(ref))
 
 
 @pytest.mark.gpu
@@ -57,28 +85,45 @@ def test_fused_kernels_match_the_reference_module():
     the float32 reference ANY bf16 execution of this network sits near 10 % norm-wise in the early layers (eager
     autocast: cosine 0.993 / 12 %, these kernels: 0.996 / 9 %, gpurun_out/r02y); held to cosine >= 0.99 and 15 %, and
     in the test below to no worse than eager bf16 autocast."""
-    m, g = _load("cuda")
+    _check_fused_against(GOLDEN)
+
+
+@pytest.mark.gpu
+def test_fused_kernels_match_the_reference_module_over_many_tiles():
+    """The same bounds on the multi-image, multi-tile fixture (2 x 16 tiles of 256 pixels; image 1 has sample
+    coordinates up to +-2.5, beyond the +-256-revolution domain of v_sin_f32 at the highest octave)."""
+    _check_fused_against(GOLDEN_MULTITILE)
+
+
+def _check_fused_against(fixture):
+    m, g = _load("cuda", fixture=fixture)
     bg, grads = _run(m, g, "cuda")
     spread = np.abs(g["bg"] - 100.0).max()
     assert np.abs(bg - g["bg"]).max() <= 2e-2 * spread, (np.abs(bg - g["bg"]).max(), spread)
     for k, v in grads.items():
+        if not g.has("grad/" + k):
+            continue
         ref = g["grad/" + k].reshape(v.shape)
         assert _cos(v, ref) >= 0.99, (k, _cos(v, ref))
         assert np.linalg.norm(v - ref) <= 0.15 * np.linalg.norm(ref), (k, np.linalg.norm(v - ref) / np.linalg.norm(ref))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 96, 80), (1, 37, 53), (3, 128, 128)])
-def test_fused_kernels_match_eager_fp32_on_ragged_images(shape):
+@pytest.mark.parametrize("shape,coord_range", [((2, 96, 80), 1.0), ((1, 37, 53), 1.0), ((3, 128, 128), 1.0),
+                                               ((2, 64, 72), 3.5)])
+def test_fused_kernels_match_eager_fp32_on_ragged_images(shape, coord_range):
     """Image sizes that are not multiples of the 128-pixel tile; the stand-in's own seeded weights; eager float32 on
     the same device as the reference, and eager bf16 autocast as the yardstick of what the dtype costs: the fused
-    kernels may not be further from float32 than 1.25 x the eager bf16 run (+ 1 %)."""
+    kernels may not be further from float32 than 1.25 x the eager bf16 run (+ 1 %).  (The reference of THIS test is
+    eager float32 torch on the same device, not a fixture: it checks tiling and raggedness; the arithmetic is pinned by
+    the reference-made fixtures above.)  coord_range > 1: sample coordinates outside [-1, 1] (cropped / jittered
+    pixelcoords) -- 2^8 x then leaves the +-256-revolution domain of v_sin_f32 / v_cos_f32 and must be range-reduced."""
     import __graft_entry__  # noqa: F401
     from ava256_amd.trainloop import BackgroundMLPStandIn
     B, H, W = shape
     gen = torch.Generator().manual_seed(B * 1000 + H)
     cam, idx = torch.randint(0, 5, (B,), generator=gen).cuda(), torch.randint(0, 3, (B,), generator=gen).cuda()
-    sc = (torch.rand(B, H, W, 2, generator=gen) * 2 - 1).cuda()
+    sc = ((torch.rand(B, H, W, 2, generator=gen) * 2 - 1) * coord_range).cuda()
     gout = torch.randn(B, 3, H, W, generator=gen).cuda()
     res = []
     for fused, dt in ((True, torch.bfloat16), (False, None), (False, torch.bfloat16)):
