@@ -8,9 +8,17 @@ scope for this build, so this module keeps the LOOP fait
 the conv decoder would be:
 
   SlabDecoderStandIn   emits the same `decout` dict a DecoderAssembler emits (models/decoders/assembler.py:263-269:
-                       template [B,K,8,8,8,4] = cat(relu(rgb*25+100), relu(alpha)), primpos, primrot, primscale) from
-                       per-primitive parameters and a per-frame code; ~2k parameters per primitive, so K=16384 gives
-                       a 134 MB gradient all-reduce -- the same order as ava-256's 187.5 MB.
+                       verts, template [B,K,8,8,8,4] = cat(relu(rgb*25+100), relu(alpha)), primpos, primrot, primscale)
+                       from per-primitive parameters and a per-frame code; ~2k parameters per primitive, so K=16384
+                       gives a 134 MB gradient all-reduce -- the same order as ava-256's 187.5 MB (SURVEY.md section
+                       2.3).  Its GEOMETRY BRANCH has the control flow of assembler.py:100-109,143-253: a predicted
+                       guide mesh (returned as `verts`, trained by `vertl1`), replaced by the ground-truth mesh while
+                       `gt_geo` is given; primitives placed on the guide mesh; the `adaptwarps` running average of
+                       2 / (neighbour distance on the mesh) as primitive scale (the one thing that does not shard by
+                       camera, SURVEY.md 8e: here an explicit K-float MAX all-reduce keeps every rank's buffer equal to
+                       the single-process one); `residuals_weight` on the pose residuals.
+  CodeEncoderStandIn   the VAE bottleneck (models/bottlenecks/vae.py:22-58): mu = W x * 0.1, logstd = W' x * 0.01,
+                       z = mu + exp(logstd) * noise in training; gives `kldiv` its (expr_mu, expr_logstd) pair.
   ColorCalStandIn      per-camera + per-identity colour affine with the reference's parametrisation
                        (models/colorcals/colorcal.py:11-31).
   BackgroundMLPStandIn per-pixel background network with the reference's shape (models/bg/mlp2d.py:19-72: two small
@@ -40,18 +48,64 @@ def mean_ell_1(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     return (pred - gt).abs().mean()
 
 
+def kl_loss_stable(mu: torch.Tensor, logstd: torch.Tensor) -> torch.Tensor:
+    """models/bottlenecks/vae.py:17-19 of the reference."""
+    return torch.mean(-0.5 + torch.abs(logstd) + 0.5 * mu ** 2 + 0.5 * torch.exp(-2.0 * torch.abs(logstd)), dim=-1)
+
+
+# configs/config.yaml:17-21 of the reference
+REFERENCE_LOSS_WEIGHTS = {"irgbl1": 1.0, "vertl1": 0.1, "kldiv": 1.0e-3, "primvolsum": 0.01}
+
+
+def _nearest_two(points: torch.Tensor) -> torch.Tensor:
+    """[K,2] indices of every point's two nearest other points (brute force in row blocks; construction time only)."""
+    K = points.shape[0]
+    out = torch.empty((K, 2), dtype=torch.int64)
+    for i in range(0, K, 2048):
+        D = torch.cdist(points[i:i + 2048].double(), points.double())
+        D[torch.arange(D.shape[0]), torch.arange(i, i + D.shape[0])] = float("inf")
+        idx = D.topk(min(2, K - 1), largest=False).indices
+        out[i:i + 2048] = idx if idx.shape[1] == 2 else idx.expand(-1, 2)
+    return out
+
+
+class CodeEncoderStandIn(nn.Module):
+    """VAE bottleneck with the reference's squashing constants and sampling rule (models/bottlenecks/vae.py:22-58)."""
+
+    def __init__(self, in_dim: int = 16, out_dim: int = 16, mean_squash: float = 0.1, std_squash: float = 0.01,
+                 seed: int = 0):
+        super().__init__()
+        self.mu, self.logstd = nn.Linear(in_dim, out_dim), nn.Linear(in_dim, out_dim)
+        self.mean_squash, self.std_squash = mean_squash, std_squash
+        g = torch.Generator().manual_seed(seed + 31)  # seeded: identical on every rank
+        with torch.no_grad():
+            for m in (self.mu, self.logstd):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * math.sqrt(1.0 / in_dim))
+                m.bias.zero_()
+
+    def forward(self, x, noise=None):
+        mu = self.mu(x) * self.mean_squash
+        logstd = self.logstd(x) * self.std_squash
+        if self.training:
+            z = mu + torch.exp(logstd) * (torch.randn_like(logstd) if noise is None else noise)
+        else:
+            z = mu
+        return z, mu, logstd
+
+
 class SlabDecoderStandIn(nn.Module):
-    def __init__(self, K: int, slab: int = 8, code_dim: int = 16, seed: int = 0):
+    def __init__(self, K: int, slab: int = 8, code_dim: int = 16, seed: int = 0, geometry: bool = True,
+                 alpha_init: float = 0.5, volradius: float = 256.0, vertstd: float = 10.0):
         super().__init__()
         base = make_primitives(1, K, device="cpu", seed=seed, slab=slab)
-        self.K, self.slab = K, slab
+        self.K, self.slab, self.geometry, self.volradius = K, slab, geometry, float(volradius)
         self.register_buffer("base_pos", base["primpos"][0].clone())
         self.register_buffer("base_rot", base["primrot"][0].clone())
         self.register_buffer("base_scale", base["primscale"][0].clone())
         g = torch.Generator().manual_seed(seed + 17)
         # pre-activation slabs with the random-init statistics of the real decoder heads
         self.rgb = nn.Parameter(torch.randn(K, slab, slab, slab, 3, generator=g))
-        self.alpha = nn.Parameter(0.5 + 0.1 * torch.randn(K, slab, slab, slab, 1, generator=g))
+        self.alpha = nn.Parameter(alpha_init * (1.0 + 0.2 * torch.randn(K, slab, slab, slab, 1, generator=g)))
         self.pos_delta = nn.Parameter(torch.zeros(K, 3))
         self.rotvec = nn.Parameter(torch.zeros(K, 3))
         self.logscale = nn.Parameter(torch.zeros(K, 3))
@@ -59,18 +113,75 @@ class SlabDecoderStandIn(nn.Module):
         with torch.no_grad():  # seeded like everything else: identical on every rank and in every process
             self.gain.weight.copy_(0.01 * torch.randn(K, code_dim, generator=g))
             self.gain.bias.zero_()
+        if geometry:
+            # Guide mesh with one vertex per primitive (the shell points, in the millimetre units of the dataset);
+            # every primitive sits on the triangle (itself, its two nearest neighbours) -- the stand-in's idxim / barim
+            # (assembler.py:118-122) -- and measures its size against those neighbours (assembler.py:147-158,183-194).
+            self.register_buffer("vertmean", self.base_pos * self.volradius)
+            self.register_buffer("vertstd", torch.tensor(float(vertstd)))
+            nn2 = _nearest_two(self.base_pos)
+            self.register_buffer("tri_idx", torch.cat([torch.arange(K)[:, None], nn2], dim=1))     # [K,3]
+            self.register_buffer("tri_bar", torch.tensor([0.9, 0.05, 0.05]).expand(K, 3).clone())
+            self.register_buffer("adaptwarps", torch.zeros(K))                                     # assembler.py:66
+            self.geo_head = nn.Linear(code_dim, K * 3)
+            with torch.no_grad():
+                self.geo_head.weight.copy_(0.02 * torch.randn(K * 3, code_dim, generator=g))
+                self.geo_head.bias.zero_()
 
-    def forward(self, code: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def _update_adaptwarps(self, pm: torch.Tensor, store: bool) -> torch.Tensor:
+        """assembler.py:183-199: size of a primitive = the larger distance to its two mesh neighbours, maximum over the
+        batch; adaptwarps <- 2 / size the first time, 0.9 * old + 0.1 * new afterwards.  The reference computes this per
+        rank and lets DDP's buffer broadcast overwrite it with rank 0's; here the batch maximum is taken over ALL ranks
+        (one K-float MAX all-reduce), so every rank holds what a single process would on the whole batch, with
+        broadcast_buffers off.  No host synchronisation (the reference's `.max().item() == 0`)."""
+        n1, n2 = self.tri_idx[:, 1], self.tri_idx[:, 2]
+        cs = torch.maximum((pm[:, n1] - pm).norm(dim=-1), (pm[:, n2] - pm).norm(dim=-1)).amax(dim=0)  # [K]
+        if store:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(cs, op=dist.ReduceOp.MAX)
+        warps_vec = 2.0 / cs
+        fresh = (self.adaptwarps.max() == 0)
+        new = torch.where(fresh, warps_vec, self.adaptwarps * 0.9 + 0.1 * warps_vec)
+        if store:
+            self.adaptwarps.copy_(new)
+            return self.adaptwarps
+        # not the running-average phase: the stored buffer, or -- never initialised -- this batch's own value
+        return torch.where(fresh, warps_vec, self.adaptwarps)
+
+    def forward(self, code: torch.Tensor, schedule: Optional[Dict[str, object]] = None,
+                gt_geo: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """`schedule` = forward_schedule(iternum) (ddp-train.py:371-377); `gt_geo` = the batch's normalised vertices,
+        used as the guide mesh while schedule["use_gt_geo"] (assembler.py:105-109)."""
         B = code.shape[0]
+        sch = schedule or {}
+        rw = min(max(float(sch.get("residuals_weight", 1.0)), 0.0), 1.0)     # assembler.py:241
         gain = 1.0 + 0.1 * torch.tanh(self.gain(code))                      # [B,K]
         rgb = torch.relu(self.rgb * 25.0 + 100.0)                            # assembler.py:261
         alpha = torch.relu(self.alpha)
         template = torch.cat([rgb[None] * gain[:, :, None, None, None, None],
                               alpha[None].expand(B, -1, -1, -1, -1, -1)], dim=-1).contiguous()
-        primpos = (self.base_pos + 0.01 * self.pos_delta)[None].expand(B, -1, -1).contiguous()
-        primrot = torch.matmul(self.base_rot, rodrigues(0.1 * self.rotvec))[None].expand(B, -1, -1, -1).contiguous()
-        primscale = (self.base_scale * torch.exp(0.1 * self.logscale))[None].expand(B, -1, -1).contiguous()
-        return {"template": template, "primpos": primpos, "primrot": primrot, "primscale": primscale}
+        pos_res, rot_res, scale_res = 0.01 * self.pos_delta, 0.1 * self.rotvec, torch.exp(0.1 * self.logscale)
+        if rw < 1.0:                                                          # assembler.py:242-245
+            pos_res, rot_res, scale_res = pos_res * rw, rot_res * rw, scale_res * rw + (1.0 - rw)
+        out = {}
+        if self.geometry:
+            geo = self.geo_head(code).view(B, self.K, 3) * self.vertstd + self.vertmean      # assembler.py:100-103
+            out["verts"] = geo
+            guide = geo
+            if gt_geo is not None and sch.get("use_gt_geo", False):
+                guide = gt_geo * self.vertstd + self.vertmean                                # assembler.py:105-109
+            pm = (self.tri_bar[None, :, :, None] * guide[:, self.tri_idx]).sum(dim=2) / self.volradius
+            with torch.no_grad():
+                aw = self._update_adaptwarps(pm, bool(sch.get("running_avg_scale", False)))
+            primpos = (pm + pos_res[None]).contiguous()
+            primscale = ((aw * 0.8)[None, :, None] * scale_res[None]).expand(B, -1, -1).contiguous()
+        else:
+            primpos = (self.base_pos + pos_res)[None].expand(B, -1, -1).contiguous()
+            primscale = (self.base_scale * scale_res)[None].expand(B, -1, -1).contiguous()
+        primrot = torch.matmul(self.base_rot, rodrigues(rot_res))[None].expand(B, -1, -1, -1).contiguous()
+        out.update(template=template, primpos=primpos, primrot=primrot, primscale=primscale)
+        return out
 
 
 class ColorCalStandIn(nn.Module):
@@ -172,15 +283,18 @@ class BackgroundMLPStandIn(nn.Module):
             return fused_background_mlp(samplecoords, bias1, lin[0].weight[:, 80:], [(m.weight, m.bias) for m in lin[1:5]],
                                         lin[5].weight, lin[5].bias)
         use_amp = dev.type == "cuda" and self.autocast_dtype is not None
+        wdt = self.cammod[0].weight.dtype  # float32; float64 in the tests' replay of a training step
         with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype or torch.bfloat16, enabled=use_amp):
-            camenc = self.cammod(torch.nn.functional.one_hot(camindex, self.ncams).float())
-            idenc = self.idmod(torch.nn.functional.one_hot(idindex, self.nident).float())
+            camenc = self.cammod(torch.nn.functional.one_hot(camindex, self.ncams).to(wdt))
+            idenc = self.idmod(torch.nn.functional.one_hot(idindex, self.nident).to(wdt))
             posenc = torch.cat([torch.sin(2 ** i * math.pi * samplecoords) for i in range(10)] +
                                [torch.cos(2 ** i * math.pi * samplecoords) for i in range(10)], dim=-1)   # mlp2d.py:64-68
             x = torch.cat([camenc[:, None, None, :].expand(b, h, w, 40).to(posenc.dtype),
                            idenc[:, None, None, :].expand(b, h, w, 40).to(posenc.dtype), posenc], dim=-1)
             out = self.mlp(x)                                                       # [b,h,w,3]
-        return out.float().permute(0, 3, 1, 2) * 25.0 + 100.0
+        if out.dtype in (torch.bfloat16, torch.float16):
+            out = out.float()
+        return out.permute(0, 3, 1, 2) * 25.0 + 100.0
 
 
 class RaymarchTrainModel(nn.Module):
@@ -190,18 +304,22 @@ class RaymarchTrainModel(nn.Module):
 
     def __init__(self, decoder: nn.Module, volradius: float = 256.0, dt: float = 1.0,
                  renderer: Optional[Callable] = None, colorcal: Optional[nn.Module] = None,
-                 bgmodel: Optional[nn.Module] = None):
+                 bgmodel: Optional[nn.Module] = None, encoder: Optional[nn.Module] = None):
         super().__init__()
         self.decoder = decoder
+        self.encoder = encoder
         self.raymarcher = Raymarcher(volradius, dt)
         self.colorcal = colorcal
         self.bgmodel = bgmodel
         self._renderer = renderer  # CPU tests inject a pure-torch stand-in; None = the gfx950 kernels
 
     def forward(self, camrot, campos, focal, princpt, pixelcoords, code, schedule=None, camindex=None, idindex=None,
-                bg=None):
-        self.last_schedule = schedule  # ddp-train.py:371-377; consumed by a real decoder's geometry branch
-        decout = self.decoder(code)
+                bg=None, gt_verts=None, noise=None):
+        self.last_schedule = schedule  # ddp-train.py:371-377; consumed by the decoder's geometry branch
+        expr_mu = expr_logstd = None
+        if self.encoder is not None:                                                 # autoencoder.py: VAE bottleneck
+            code, expr_mu, expr_logstd = self.encoder(code, noise)
+        decout = self.decoder(code, schedule=schedule, gt_geo=gt_verts)
         if self._renderer is not None:
             rayrgb, rayalpha = self._renderer(camrot, campos, focal, princpt, pixelcoords, decout)
         else:
@@ -217,14 +335,15 @@ class RaymarchTrainModel(nn.Module):
             bg = self.bgmodel(camindex, idindex, samplecoords)
         if bg is not None:                                                           # autoencoder.py:263-265
             rayrgb = rayrgb + (1.0 - rayalpha) * bg
-        return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"], "bg": bg}
+        return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"], "bg": bg,
+                "verts": decout.get("verts"), "expr_mu": expr_mu, "expr_logstd": expr_logstd}
 
 
 def forward_schedule(iternum: int) -> Dict[str, object]:
     """Forward-pass switches of the first iterations, ddp-train.py:371-377: for iternum < 100 the decoder is driven
     with `running_avg_scale=True`, ground-truth geometry (`gt_geo = verts`) and `residuals_weight = 0`; afterwards
-    `False`, `None`, `1.0`.  Returned as (running_avg_scale, use_gt_geo, residuals_weight); the Trainer hands them to a
-    model whose forward takes a `schedule` keyword (the stand-in decoder has no geometry branch and ignores them)."""
+    `False`, `None`, `1.0`.  The Trainer hands them to the model, whose decoder consumes all three
+    (SlabDecoderStandIn.forward: running average of `adaptwarps`, ground-truth guide mesh, residual weight)."""
     warm = iternum < 100
     return {"running_avg_scale": warm, "use_gt_geo": warm, "residuals_weight": 0.0 if warm else 1.0}
 
@@ -247,25 +366,38 @@ class Trainer:
         self.optim = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999))
         self.sched = torch.optim.lr_scheduler.StepLR(self.optim, step_size=lr_scheduler_iter, gamma=gamma)
         self.clip = clip
-        self.loss_weights = loss_weights or {"irgbl1": 1.0, "primvolsum": 0.01}  # configs/config.yaml:17-21
+        self.loss_weights = dict(loss_weights or REFERENCE_LOSS_WEIGHTS)  # configs/config.yaml:17-21
         self.iternum = 0
         self._clipper = None
         self.last_grad_norm = None
 
     def losses(self, output, batch):
+        """ddp-train.py:404-418.  A term whose inputs the model does not produce (no geometry branch, no VAE pair) is
+        skipped, like a key absent from the reference's `loss_weights`."""
         out = {}
         if "irgbl1" in self.loss_weights:
             out["irgbl1"] = mean_ell_1(output["irgbrec"], batch["image"])
-        if "primvolsum" in self.loss_weights:  # ddp-train.py:413-415
+        if "vertl1" in self.loss_weights and output.get("verts") is not None and "verts" in batch:
+            dec = self.raw_model.decoder
+            out["vertl1"] = mean_ell_1(output["verts"], batch["verts"] * dec.vertstd + dec.vertmean)
+        if "primvolsum" in self.loss_weights:
             out["primvolsum"] = torch.sum(torch.prod(1.0 / output["primscale"], dim=-1), dim=-1)
+        if "kldiv" in self.loss_weights and output.get("expr_mu") is not None:
+            out["kldiv"] = kl_loss_stable(output["expr_mu"], output["expr_logstd"])
+        if not out:
+            raise ValueError("No losses were computed. We can't train like that!")
         return out
+
+    def total_loss(self, losses):
+        """ddp-train.py:424-430 (no (value, weight) tuples on this path: every term is a plain mean)."""
+        return sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
 
     def step(self, batch: Dict[str, torch.Tensor]):
         output = self.model(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
                             batch["code"], schedule=forward_schedule(self.iternum), camindex=batch.get("camindex"),
-                            idindex=batch.get("idindex"))
+                            idindex=batch.get("idindex"), gt_verts=batch.get("verts"), noise=batch.get("noise"))
         losses = self.losses(output, batch)
-        loss = sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
+        loss = self.total_loss(losses)
         self.optim.zero_grad(set_to_none=False)
         loss.backward()
         # NaN / Inf -> 0 in every gradient, then clip the global 2-norm (ddp-train.py:436-441: two masked assignments
@@ -303,11 +435,16 @@ def make_training_batch(N, H, W, K, device, seed=1112, code_dim=16, target_decod
     batch["code"] = torch.randn(N, code_dim, device=device, generator=g)
     batch["camindex"] = torch.arange(N, device=device) % ncams
     batch["idindex"] = (torch.arange(N, device=device) // ncams) % nident
+    # normalised ground-truth vertices (one per primitive of the stand-in's guide mesh; SURVEY.md appendix D `verts`)
+    # and the VAE's sampling noise, drawn here so that a replay of the step sees the same numbers
+    batch["verts"] = 0.05 * torch.randn(N, K, 3, device=device, generator=g)
+    batch["noise"] = torch.randn(N, code_dim, device=device, generator=g)
     if target_decoder is not None:
         tm = RaymarchTrainModel(target_decoder.to(device))
         bgt = torch.full((N, 3, H, W), float(target_bg), device=device)
         batch["image"] = tm(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
-                            batch["code"], bg=bgt)["irgbrec"].clone()
+                            batch["code"], bg=bgt, gt_verts=batch["verts"],
+                            schedule={"use_gt_geo": True})["irgbrec"].clone()
     else:
         batch["image"] = torch.zeros(N, 3, H, W, device=device)
     return batch, cams["volradius"]

@@ -15,9 +15,10 @@ collective (render/march units are independent: SURVEY.md section 8e) -- the onl
 leg are the barriers and the MAX-reduce of the elapsed time.
 
 The same line carries a `train` object: iterations/s of the reference-shaped optimisation loop
-(ava-256_amd/trainloop.py: stand-in decoder -> rays -> march -> colour calibration -> bf16 background MLP ->
-matting -> L1 + primvolsum -> backward -> NaN mask -> clip -> Adam; DDP all-reduce of parameter gradients over
-RCCL when N>1), measured after the march leg on the same process group.
+(ava-256_amd/trainloop.py: VAE bottleneck -> stand-in decoder with a geometry branch (guide mesh, adaptwarps running
+average, the schedule of the first 100 iterations) -> rays -> march -> colour calibration -> bf16 background MLP ->
+matting -> irgbl1 + vertl1 + primvolsum + kldiv -> backward -> NaN mask -> clip -> Adam; DDP all-reduce of parameter
+gradients over RCCL when N>1), measured after the march leg on the same process group.
 
 The control flow (init, warm-up, barrier + synchronize, timed steps, MAX over ranks, rank-0 line) lives in
 `run_timed` / `main` and takes the process-group backend and the step factory as arguments, so that
@@ -202,14 +203,15 @@ def kernel_averages(events):
 def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg):
     """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object."""
     from ava256_amd import _hooks as mm
-    from ava256_amd.trainloop import (BackgroundMLPStandIn, ColorCalStandIn, RaymarchTrainModel, SlabDecoderStandIn,
-                                      Trainer, make_training_batch)
+    from ava256_amd.trainloop import (BackgroundMLPStandIn, CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel,
+                                      SlabDecoderStandIn, Trainer, make_training_batch)
     N, H, W, K, slab = WORKLOADS[workload]
     ncams, nident = 80, 4
     batch, volradius = make_training_batch(N, H, W, K, dev, seed=1112 + rank, ncams=ncams, nident=nident,
                                            target_decoder=SlabDecoderStandIn(K, slab, seed=9))
     model = RaymarchTrainModel(SlabDecoderStandIn(K, slab, seed=1), volradius, colorcal=ColorCalStandIn(ncams, nident),
-                               bgmodel=BackgroundMLPStandIn(ncams, nident) if with_bg else None).to(dev)
+                               bgmodel=BackgroundMLPStandIn(ncams, nident) if with_bg else None,
+                               encoder=CodeEncoderStandIn()).to(dev)
     nparams = sum(p.numel() for p in model.parameters())
     tr = Trainer(model, ddp=world > 1, device_ids=[local_rank] if world > 1 else None)
     state = {}

@@ -1,7 +1,9 @@
 """Parity at the BASELINE.json configuration sizes.
 
 * C1 (4 cams, 128x128, K=512), one camera of C2 (512x512, K=4096, at alpha gain 1 and 20), a one-camera slice of C3/C5
-  (512x512, K=16384) and one camera of C4 (1024x1024, K=8192) go through the float64 oracle: forward + all gradients.
+  (512x512, K=16384) and one camera of C4 (1024x1024, K=8192) go through the float64 oracle: forward + all gradients;
+  so do an 8-camera slice of C2 (the whole-image-per-XCD regime of the block mapping) and C3/C5 and C4 at their FULL
+  per-GPU batch of 4 (two XCDs per image).
 * C3/C5 and C4 at their full per-GPU batch (N=4) are checked through properties + kernel diagnostics.
 * C2 (80 cams, 512x512, K=4096 -- the bench workload) is checked through size-independent properties:
     - tile independence: rendering a sub-rectangle of pixels gives bit-identical rays (packets differ, rays do not);
@@ -39,6 +41,9 @@ ORACLE_CONFIGS = [
     ("C2cam", 1, 512, 512, 4096, 1.0), ("C2cam_a20", 1, 512, 512, 4096, 20.0),      # one camera of the bench workload
     ("C3slice", 1, 512, 512, 16384, 6.0),
     ("C4cam", 1, 1024, 1024, 8192, 1.0), ("C4cam_a12", 1, 1024, 1024, 8192, 12.0),  # 16384 packets/image, K between the tuned sizes
+    # the block -> work mappings at configuration size (DESIGN.md 3.3 "Which XCD renders what"): N >= 8 = whole images
+    # per XCD (forward) / all primitives of an image on one XCD (backward); N = 4 = two XCDs per image (F = 2)
+    ("C2x8_a20", 8, 512, 512, 4096, 20.0), ("C3full", 4, 512, 512, 16384, 6.0), ("C4full_a12", 4, 1024, 1024, 8192, 12.0),
 ]
 
 
@@ -84,8 +89,9 @@ def test_config_sizes_against_oracle(cfg, oracle64, oracle32):
     assert np.abs(npf(t["template"].grad) - gt).max() <= 1e-3 * np.abs(gt).max()
     # Pose gradients on white-noise slabs cancel heavily, so the honest yardstick is the SAME algorithm in the SAME
     # arithmetic type: the float32 build of the oracle (the reference's per-ray loop in fp32, incremental t) against
-    # float64.  Absolute bounds: cosine >= 0.9999, norm-wise 1e-2, max-abs 1e-1; relative bound: the HIP kernels may
-    # not be worse than 2x the fp32 oracle's own norm-wise error (+1e-4).
+    # float64.  Absolute bounds: cosine >= 0.9999, norm-wise 8e-3 (measured over all configurations: kernels
+    # 0.4-5.5e-3, fp32 oracle 0.9e-3-1.2e-2), max-abs 1e-1; relative bound: the HIP kernels may not be worse than 2x the
+    # fp32 oracle's own norm-wise error (+1e-4).
     ref32, sat32, _ = oracle32.march_forward(*a)
     g32 = oracle32.march_backward(*a, sat32, gout)
     for mine, refg, o32, nm in ((t["primpos"].grad, gp, g32[0], "pos"), (t["primrot"].grad, gr, g32[1], "rot"),
@@ -93,10 +99,11 @@ def test_config_sizes_against_oracle(cfg, oracle64, oracle32):
         m = npf(mine)
         e_hip = np.linalg.norm(m - refg) / np.linalg.norm(refg)
         e_o32 = np.linalg.norm(o32.astype(np.float64) - refg) / np.linalg.norm(refg)
-        print("   %s grad_%s: HIP norm-wise %.2e, fp32 oracle %.2e, HIP vs fp32 oracle %.2e" % (
-            name, nm, e_hip, e_o32, np.linalg.norm(m - o32) / np.linalg.norm(refg)))
+        print("   %s grad_%s: HIP norm-wise %.2e (max-abs %.2e), fp32 oracle %.2e, HIP vs fp32 oracle %.2e" % (
+            name, nm, e_hip, np.abs(m - refg).max() / np.abs(refg).max(), e_o32,
+            np.linalg.norm(m - o32) / np.linalg.norm(refg)))
         assert cosine(m, refg) >= 0.9999
-        assert e_hip <= 1e-2
+        assert e_hip <= 8e-3
         assert e_hip <= 2.0 * e_o32 + 1e-4, (nm, e_hip, e_o32)
         assert np.abs(m - refg).max() <= 1e-1 * np.abs(refg).max()
 

@@ -30,17 +30,57 @@ def _batch(N, H, W, seed, code_dim=16):
     return b
 
 
+def _golden_loss():
+    return np.load(os.path.join(ROOT, "tests", "golden", "trainstep_loss.npz"))
+
+
+def test_loss_formula_is_the_references_own():
+    """Trainer.losses / Trainer.total_loss against tests/golden/trainstep_loss.npz: the reference's statements
+    ddp-train.py:404-430 executed by tests/golden/gen_trainstep.py (float64) with the weights of configs/config.yaml:17-21
+    -- every term (irgbl1, vertl1 with its de-normalisation, primvolsum, kldiv) and the weighted total."""
+    import types
+    from ava256_amd.trainloop import REFERENCE_LOSS_WEIGHTS, Trainer
+    g = _golden_loss()
+    weights = dict(zip(g["weight_names"].tolist(), g["weight_values"].tolist()))
+    assert REFERENCE_LOSS_WEIGHTS == weights
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    tr = Trainer.__new__(Trainer)
+    tr.loss_weights = dict(REFERENCE_LOSS_WEIGHTS)
+    tr.raw_model = types.SimpleNamespace(decoder=types.SimpleNamespace(vertstd=t(g["vertstd"]), vertmean=t(g["vertmean"])))
+    output = {k[4:]: t(g[k]) for k in g.files if k.startswith("out/")}
+    batch = {k[5:]: t(g[k]) for k in g.files if k.startswith("data/")}
+    losses = tr.losses(output, batch)
+    assert sorted(losses) == sorted(k[5:] for k in g.files if k.startswith("term/"))
+    for k, v in losses.items():
+        assert v.shape == g["term/" + k].shape and np.allclose(v.numpy(), g["term/" + k], rtol=1e-13, atol=0), k
+    assert abs(float(tr.total_loss(losses)) - float(g["loss"])) <= 1e-12 * abs(float(g["loss"]))
+    # a model without a geometry branch / VAE pair computes only the terms it has the inputs for
+    output.update(verts=None, expr_mu=None, expr_logstd=None)
+    assert sorted(tr.losses(output, batch)) == ["irgbl1", "primvolsum"]
+
+
+def _f64(batch):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+
+
 def test_loop_semantics_cpu():
-    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer, mean_ell_1
+    import copy
+    from ava256_amd.trainloop import (CodeEncoderStandIn, RaymarchTrainModel, SlabDecoderStandIn, Trainer,
+                                      forward_schedule, mean_ell_1)
     torch.manual_seed(0)
-    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer)
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer, encoder=CodeEncoderStandIn())
     tr = Trainer(model, lr=2e-4, lr_scheduler_iter=2, gamma=1.4, clip=1.0)
     assert isinstance(tr.optim, torch.optim.Adam) and tr.optim.defaults["betas"] == (0.9, 0.999)
-    assert tr.loss_weights == {"irgbl1": 1.0, "primvolsum": 0.01}            # configs/config.yaml:17-21
+    assert tr.loss_weights == {"irgbl1": 1.0, "vertl1": 0.1, "kldiv": 1.0e-3, "primvolsum": 0.01}  # configs/config.yaml:17-21
     b = _batch(3, 8, 8, 0)
-    out = model(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], b["code"])
-    ref = 1.0 * mean_ell_1(out["irgbrec"], b["image"]) + 0.01 * torch.mean(
-        torch.sum(torch.prod(1.0 / out["primscale"], dim=-1), dim=-1))      # ddp-train.py:404-430
+    # the loss of the step = the (reference-pinned, see above) formula on the model's outputs at iteration 0
+    twin = copy.deepcopy(model)
+    out = twin(b["camrot"], b["campos"], b["focal"], b["princpt"], b["pixelcoords"], b["code"],
+               schedule=forward_schedule(0), gt_verts=b["verts"], noise=b["noise"])
+    twin_tr = Trainer(twin)
+    terms = twin_tr.losses(out, b)
+    assert sorted(terms) == ["irgbl1", "kldiv", "primvolsum", "vertl1"]
+    ref = twin_tr.total_loss(terms)
     loss, parts = tr.step(b)
     assert torch.allclose(loss, ref.detach(), rtol=1e-6)
     # StepLR(step_size=2, gamma=1.4): lr after 2 steps = 2e-4 * 1.4
@@ -69,6 +109,45 @@ def test_forward_schedule_of_the_first_iterations():
     tr.iternum = 100
     tr.step(b)
     assert model.last_schedule == forward_schedule(100) and tr.iternum == 101
+
+
+def test_decoder_consumes_the_schedule():
+    """What the three switches do inside the decoder (assembler.py:105-109,183-199,241-253): ground-truth guide mesh,
+    running average of adaptwarps (first value assigned, then 0.9 / 0.1), residual weight 0 = pose residuals off."""
+    from ava256_amd.trainloop import SlabDecoderStandIn, forward_schedule
+    torch.manual_seed(3)
+    dec = SlabDecoderStandIn(16, seed=2)
+    with torch.no_grad():
+        dec.pos_delta.normal_(), dec.rotvec.normal_(), dec.logscale.normal_()
+    code, gt = torch.randn(3, 16), 0.1 * torch.randn(3, 16, 3)
+    warm, late = forward_schedule(0), forward_schedule(100)
+    assert float(dec.adaptwarps.max()) == 0.0
+    o1 = dec(code, schedule=warm, gt_geo=gt)
+    # guide mesh = ground truth: placement does not depend on the predicted geometry, which is still returned
+    guide = gt * dec.vertstd + dec.vertmean
+    pm = (dec.tri_bar[None, :, :, None] * guide[:, dec.tri_idx]).sum(2) / dec.volradius
+    assert torch.allclose(o1["primpos"], pm, atol=1e-7)                      # residuals_weight = 0: no position residual
+    assert torch.allclose(o1["verts"], dec.geo_head(code).view(3, 16, 3) * dec.vertstd + dec.vertmean)
+    n1, n2 = dec.tri_idx[:, 1], dec.tri_idx[:, 2]
+    cs = torch.maximum((pm[:, n1] - pm).norm(dim=-1), (pm[:, n2] - pm).norm(dim=-1)).amax(0)
+    aw1 = 2.0 / cs
+    assert torch.allclose(dec.adaptwarps, aw1)                               # first time: assigned (assembler.py:195-196)
+    assert torch.allclose(o1["primscale"], (aw1 * 0.8)[None, :, None].expand(3, 16, 3))  # scale residual -> 1 at rw = 0
+    assert torch.allclose(o1["primrot"], dec.base_rot[None].expand(3, -1, -1, -1), atol=1e-5)
+    gt2 = 0.1 * torch.randn(3, 16, 3)
+    dec(code, schedule=warm, gt_geo=gt2)
+    guide2 = gt2 * dec.vertstd + dec.vertmean
+    pm2 = (dec.tri_bar[None, :, :, None] * guide2[:, dec.tri_idx]).sum(2) / dec.volradius
+    cs2 = torch.maximum((pm2[:, n1] - pm2).norm(dim=-1), (pm2[:, n2] - pm2).norm(dim=-1)).amax(0)
+    aw2 = 0.9 * aw1 + 0.1 * (2.0 / cs2)
+    assert torch.allclose(dec.adaptwarps, aw2)                               # then the running average (:197-198)
+    o3 = dec(code, schedule=late, gt_geo=gt)                                 # iteration >= 100
+    assert torch.equal(dec.adaptwarps, aw2.to(dec.adaptwarps.dtype)) or torch.allclose(dec.adaptwarps, aw2)  # frozen
+    geo = o3["verts"]
+    pm3 = (dec.tri_bar[None, :, :, None] * geo[:, dec.tri_idx]).sum(2) / dec.volradius
+    assert torch.allclose(o3["primpos"], pm3 + 0.01 * dec.pos_delta[None], atol=1e-7)    # predicted mesh + residual
+    assert torch.allclose(o3["primscale"], (dec.adaptwarps * 0.8)[None, :, None] * torch.exp(0.1 * dec.logscale)[None])
+    assert not torch.allclose(o3["primrot"], o1["primrot"], atol=1e-3)
 
 
 def test_nan_and_inf_gradients_are_zeroed():
@@ -136,19 +215,20 @@ def _ddp_worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer
-    from test_trainloop import _batch, fake_renderer
+    from ava256_amd.trainloop import CodeEncoderStandIn, RaymarchTrainModel, SlabDecoderStandIn, Trainer
+    from test_trainloop import _batch, _f64, fake_renderer
     # float64: the fake renderer's gradients are sums of +-1/numel terms that cancel; in float32 their value depends on
     # the thread-level summation order by ~1e-3, which would mask what this test is about
-    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer).double()
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer, encoder=CodeEncoderStandIn()).double()
     tr = Trainer(model, ddp=True)
-    full = {k: v.double() for k, v in _batch(4, 8, 8, 7).items()}
+    full = _f64(_batch(4, 8, 8, 7))
     shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
     tr.step(shard)
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    aw1 = model.decoder.adaptwarps.detach().clone()
     for _ in range(2):
         tr.step(shard)
-    torch.save({"state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "grads": grads},
+    torch.save({"state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "grads": grads, "aw1": aw1},
                os.path.join(outdir, "r%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -156,18 +236,23 @@ def _ddp_worker(rank, world, port, outdir):
 def test_ddp_two_ranks_match_single_process(tmp_path):
     """Only parameter gradients cross ranks; with equal shards the 2-rank result equals one process on the full batch
     (mean of shard gradients = gradient of the mean loss)."""
-    from ava256_amd.trainloop import RaymarchTrainModel, SlabDecoderStandIn, Trainer
+    from ava256_amd.trainloop import CodeEncoderStandIn, RaymarchTrainModel, SlabDecoderStandIn, Trainer
     port = _free_port()
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a = torch.load(os.path.join(str(tmp_path), "r0.pt"))
     b = torch.load(os.path.join(str(tmp_path), "r1.pt"))
     for k in a["state"]:
-        assert torch.equal(a["state"][k], b["state"][k]), k       # ranks stay in lock-step
+        assert torch.equal(a["state"][k], b["state"][k]), k       # ranks stay in lock-step (buffers included: no
+                                                                  # buffer broadcast, adaptwarps by its own all-reduce)
     # first-step gradients (after all-reduce, NaN masking and clipping) equal the single-process ones.  Parameters
     # after several Adam steps are not compared: Adam turns round-off-sized gradients into +-lr updates.
-    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer).double()
+    model = RaymarchTrainModel(SlabDecoderStandIn(8, seed=1), renderer=fake_renderer, encoder=CodeEncoderStandIn()).double()
     tr = Trainer(model)
-    tr.step({k: v.double() for k, v in _batch(4, 8, 8, 7).items()})
+    tr.step(_f64(_batch(4, 8, 8, 7)))
+    # the running average that does not shard by camera (SURVEY.md 8e; assembler.py:183-199): the batch maximum is taken
+    # over both ranks' frames (a K-float MAX all-reduce), so each rank holds the single-process value -- bit for bit
+    assert torch.equal(a["aw1"], model.decoder.adaptwarps) and torch.equal(b["aw1"], model.decoder.adaptwarps)
+    assert float(a["aw1"].min()) > 0.0
     for n, p_ in model.named_parameters():
         g = a["grads"][n]
         err = float((p_.grad - g).abs().max()) / float(g.abs().max() + 1e-300)
