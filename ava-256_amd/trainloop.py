@@ -437,7 +437,11 @@ def make_training_batch(N, H, W, K, device, seed=1112, code_dim=16, target_decod
     batch["idindex"] = (torch.arange(N, device=device) // ncams) % nident
     # normalised ground-truth vertices (one per primitive of the stand-in's guide mesh; SURVEY.md appendix D `verts`)
     # and the VAE's sampling noise, drawn here so that a replay of the step sees the same numbers
-    batch["verts"] = 0.05 * torch.randn(N, K, 3, device=device, generator=g)
+    # (one tracked FRAME seen by the batch's cameras -- "1 subject, 80 cams" -- plus a small per-image difference: the
+    # adaptwarps running average takes the maximum over the batch, assembler.py:191-192, so independent meshes per image
+    # would inflate every primitive with the batch size)
+    batch["verts"] = (0.05 * torch.randn(1, K, 3, device=device, generator=g) +
+                      0.005 * torch.randn(N, K, 3, device=device, generator=g))
     batch["noise"] = torch.randn(N, code_dim, device=device, generator=g)
     if target_decoder is not None:
         tm = RaymarchTrainModel(target_decoder.to(device))

@@ -160,14 +160,21 @@ def test_one_training_iteration_matches_the_float64_replay(oracle64, iternum):
         worst[n] = (cos, rel)
         assert cos >= 0.9999, (n, cos, rel)
         assert rel <= 1.5e-2, (n, cos, rel)
-        # Adam, first step: update = lr * g / (|g| + eps), i.e. +-lr wherever the gradient's sign is beyond doubt
-        clear = r.abs() > 1e-2 * r.abs().max()
+        # Adam, first step (m = 0.1 g, v = 0.001 g^2, both bias-corrected): update = -lr * g / (|g| + eps), eps = 1e-8.
+        # (a) the GPU step applies exactly that to ITS OWN clipped gradient;  (b) against the replay wherever the
+        # gradient is well above eps and its sign beyond doubt (below that the update is a steep function of g: a
+        # clipped gradient of 1e-8 turns a 1e-9 difference into 2.5 % of lr)
         dp_g = (p.detach() - before[n]).double().cpu()
         dp_r = rnamed[n].detach() - before[n].double().cpu()
-        ulp = np.spacing(np.float32(float(before[n].abs().max())))
-        assert float((dp_g - dp_r)[clear].abs().max()) <= 1e-2 * lr + 2.0 * float(ulp), n
-        assert float(dp_g.abs().max()) <= lr * 1.001 + 2.0 * float(ulp), n
+        ulp = float(np.spacing(np.float32(float(before[n].abs().max()))))
+        own = -lr * g / (g.abs() + 1e-8)
+        assert float((dp_g - own).abs().max()) <= 1e-3 * lr + 2.0 * ulp, n
+        clear = (r.abs() > 1e-2 * r.abs().max()) & (r.abs() > 1e-5)
+        if bool(clear.any()):
+            assert float((dp_g - dp_r)[clear].abs().max()) <= 2e-2 * lr + 2.0 * ulp, n
     assert len(worst) >= 20
+    print("iteration", iternum, "saturated", round(frac_sat, 3), "worst cos", min(v[0] for v in worst.values()),
+          "worst norm-wise", max(v[1] for v in worst.values()), "grad norm", gn, rn, "loss", float(gloss), rloss)
     # ---- the running average of the primitive sizes ----
     aw_g, aw_r = gm.decoder.adaptwarps.double().cpu(), rt.raw_model.decoder.adaptwarps
     assert float((aw_g - aw_r).abs().max()) <= 1e-5 * float(aw_r.abs().max())
