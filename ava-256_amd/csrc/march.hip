@@ -114,7 +114,10 @@ struct MarchParams {
 constexpr uint32_t kFlagListOverflow = 1u;  // some primitive received more than pl_cap packets
 constexpr uint32_t kFlagGlobal = 2u;        // a packet produced step indices that do not fit the packed keys
 constexpr uint32_t kFlagBwdHandoff = 4u;    // THIS backward handed a primitive to the ray-centric kernel (cleared per call)
+constexpr uint32_t kFlagBwdPrecise = 8u;    // THIS backward left a primitive to the two-pass kernel (cleared per call)
 constexpr uint32_t kCountDead = 0x80000000u;  // pl_count bit 31: "handed over by this backward" (cleared per call)
+constexpr uint32_t kCountPrecise = 0x40000000u;  // bit 30: "owned by the two-pass (residual) kernel in this backward"
+constexpr uint32_t kCountMask = 0x3fffffffu;     // the packets the forward counted
 constexpr uint32_t kNoSat = 0xffffffffu;
 #ifndef MVP_STRIP_ROWS
 #define MVP_STRIP_ROWS 3  // packet rows per dispatch strip (march_packet: packet -> (image, tile))
@@ -1172,7 +1175,11 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                                             y.z > -1.f && y.z < 1.f;  // primtransf.h:112-117, subset_kernel.h:84
                         if (__ballot(inside) == 0ull) continue;
                         // fallback backward: only primitives the primitive-centric kernel could not own
-                        const bool emit = !BWD || emit_all || (p.pl_count[(size_t)n * K + k] > (uint32_t)p.pl_cap);
+                        bool emit = true;
+                        if (BWD && !emit_all) {
+                            const uint32_t c_ = p.pl_count[(size_t)n * K + k];
+                            emit = (c_ & kCountDead) != 0u || (c_ & kCountMask) > (uint32_t)p.pl_cap;
+                        }
 
                         f3 gy = mk3(0.f, 0.f, 0.f);  // BWD: dL/dy of this lane's sample (0 when not inside)
                         if (BWD && WARP && inside) {
@@ -1480,7 +1487,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     if (BWD) {
         bool emit_all = p.fallback_all != 0;
         if (!emit_all) {  // nothing to do unless the forward raised a flag
-            const uint32_t flags = p.pl_count[(size_t)p.N * p.K];
+            const uint32_t flags = p.pl_count[(size_t)p.N * p.K] & ~kFlagBwdPrecise;  // (those are not this kernel's)
             if (flags == 0u) return;
             emit_all = (flags & kFlagGlobal) != 0u;
         }
@@ -1496,7 +1503,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
-//   LDS: [V] float4 template slab | [4][Vp] int32 gradient "hi" | [4][Vp] uint32 gradient "lo" |
+//   LDS: [V] float4 template slab | [4][Vp] int32 fixed-point gradient |
 //        ray queue (kQueueCap x 8 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
@@ -1512,18 +1519,38 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 //
 // Slab-gradient accumulation.  Measured on MI355X (tools/ubench/lds_atomic.hip): ds_add_f32 retires ~3 cycles
 // per ACTIVE LANE (193 cycles per wave64 instruction, any address pattern) while ds_add_u32 takes 4.8 cycles per
-// wave instruction when conflict-free.  The 32 contributions of a sample are therefore accumulated in fixed
-// point with integer LDS atomics: t = int(value * 2^e * 2^16); hi += t >> 16; lo += t, wrapping (two int32
-// accumulators per slab float; fix_value() below puts them back together).  2^e is a per-primitive, per-channel-class power of two derived from a guaranteed
-// bound B of any single contribution (|value * 2^e| < 2^14), so sums of up to 65536 contributions cannot
-// overflow; the resolution is 2^-30 * B, values are rounded to nearest.  B comes from the upstream gradients of the ray
-// packets on THIS primitive's list (packetmax_kernel), the slab's own max |rgb| and max |raysat|; it assumes sample
-// weights |alpha*fade*dt| <= 1 and |1 - alpha_before| <= 1 (true for non-negative opacity) -- a sample that breaks
-// that is detected and the primitive is handed to the ray-centric kernel.  Sums are exact integers => the slab gradient is bit-reproducible run
-// to run (the fp32-atomic formulation is not).  The exact number of samples each round can add is counted while
-// the rays are queued; before the running total could pass 65536 the integer sums are drained into a float array
-// in LDS (plain adds by the owning threads) and restart from zero, so any number of samples per primitive is fine.
-// Primitives with a non-finite bound are handed to the ray-centric kernel through the forward's overflow flag.
+// wave instruction when conflict-free.  The 32 contributions of a sample are therefore accumulated in FIXED POINT with
+// integer LDS atomics, ONE int32 word per slab float (round 3; rounds 1-2 used a hi/lo pair of words = 64 atomics per
+// sample, and the LDS pipe was busy 82 % of the kernel):  acc += rn(value * s),  s = 0.999 * 2^31 / (n * B)  where
+//   * n is the EXACT number of samples of the current round (counted while the rays are queued) and B bounds any single
+//     contribution of the round, so |sum| < 2^31: no overflow.  B = G_q * min(1, Amax * dt) for the colour channels:
+//     G_q = max |grad_rayrgba| over the ray PACKETS of the round's list entries (packetmax_kernel, one pass over the
+//     upstream gradient before this kernel), Amax = the slab's max |opacity|; a plain sample weighs
+//     alpha * fade * dt <= Amax * dt, and the sample that saturates a ray weighs 1 - alpha_before <= its own alpha * dt (it
+//     saturated BECAUSE alpha_before + alpha * dt >= 1).  Opacity channel: B = dt * (3 (Tmax + Rmax) + 1) * G_q.
+//     Resolution 2^-31 * n * B: a round of typical packets (C2: ~1200 samples) resolves 2^-20.8 of the bound; rounds are
+//     cut so that n <= 2^14 (a round takes fewer list entries when the packets' step ranges are long).
+//   * DYNAMIC RANGE.  One word resolves the round's contributions relative to the LARGEST upstream gradient near it.
+//     While it marches, the round records the smallest max |g| of the rays it really marched (rays whose upstream gradient
+//     is exactly zero contribute exact zeros and are skipped); when that is more than 256x below G_q -- an outlier pixel
+//     in one of the packets, whether its ray crosses the box or not -- the primitive is left to the TWO-PASS instantiation
+//     of this kernel (RESID; a small persistent grid launched right behind, which returns at once when no primitive was
+//     marked): every round is marched twice there, pass A's sums of rn(x) are flushed, pass B accumulates the residuals
+//     rn((x - rn(x)) * 2^31 / n) -- together 2^-62 * n^2 * B, finer than fp32.  Never on uniform or Gaussian upstream
+//     gradients (L1 / L2 image losses: P ~ 4e-8 per ray); on heavy-tailed ones it keeps every primitive exact where it
+//     matters.  (The residual scatter lives in its own instantiation because its mere presence in this kernel -- 21
+//     spilled VGPRs in a branch never taken -- cost 5 % at C2 and 15 % at C3.)
+//   * a primitive whose list needs more than one round flushes the sums at the end of every round but the last into
+//     grad_template itself (every voxel has one owner thread, at every flush and at the end, so no atomics and no second
+//     LDS array; each flush converts with its round's scale) and restarts from zero.
+// The sums are exact integers, so a round's result does not depend on the order its samples arrive in.  The forward
+// appends list entries in a different order on every run; a multi-round primitive therefore walks its entries in
+// ascending packet order (a rank sort of the keys at kernel start, indices in LDS), which makes the composition of every
+// round -- hence every scale, every pass decision and every flushed float -- the same on every run: the slab gradient is
+// BIT-REPRODUCIBLE run to run for every primitive (the fp32-atomic formulation is not; the two-word form was, up to
+// 65536 samples per primitive).
+// A sample whose weight breaks the bound (signed opacity) is detected and the primitive is handed to the ray-centric
+// kernel, like one with a non-finite bound.
 // The gradient arrays use a z stride of TH*TW + kGradPadZ words.  With the natural stride (a multiple of the 32 banks)
 // two layers of cells collide bank for bank.  Measured at C2 (tools/exp4_stats.py): a 32-lane group has ~23 active
 // lanes, at most ~2.05 of them on one address, and the busiest bank serves 3.25 lanes with pad 4 but 2.93 with pad 5
@@ -1542,12 +1569,13 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // primitive in flight than round 1's 4 x 3, 2 waves x 5 workgroups two more.  Which is faster depends on how much work a
 // primitive has: K = 16384 at 512^2 (few packets per primitive) prefers 2 waves (C3 backward 0.87 -> 0.74 ms), K = 8192 at
 // 1024^2 prefers 3 (C4 1.90 vs 2.01 ms), C2 is indifferent; the host picks by packets per primitive.
-constexpr int kFixHiBits = 14;
+constexpr float kFixRange = 0.999f * 2147483648.f;  // |sum of a round's contributions * scale| stays below 2^31
+constexpr float kTwoPassRatio = 256.f;  // marched rays' gradient magnitudes further below the bound than this: two passes
+constexpr int kRoundBudgetLog2 = 14;   // a round takes list entries while 64 lanes x their step ranges stay below 2^14
 #ifndef MVP_GRADPAD
 #define MVP_GRADPAD 5
 #endif
 constexpr int kGradPadZ = MVP_GRADPAD;  // see the note on the gradient arrays above
-constexpr uint32_t kFixMaxSamples = 65536u;
 #ifndef MVP_ENTRIES_PER_WAVE
 #define MVP_ENTRIES_PER_WAVE 5
 #endif
@@ -1557,10 +1585,10 @@ __host__ __device__ constexpr int prim_queue_cap(int pw) { return prim_entries_p
 constexpr int kLenBuckets = 32;     // rays are queued sorted by their number of lattice steps
 
 // Backward prologue.  (1) Per ray packet (8x8 pixels): max |grad_rayrgba| -> pmax[packet] as float bits (non-negative
-// floats order like uints; a NaN's pattern is larger than Inf's, so it is sticky).  The primitive-centric kernel
-// derives each primitive's fixed-point scale from the packets on ITS list, so one outlier pixel costs resolution
-// only in the primitives it touches.  (2) Undo what an earlier backward over the same forward left in the hand-off
-// buffer (retain_graph / several losses): the "handed over" bit of the counters and flag.
+// floats order like uints; a NaN's pattern is larger than Inf's, so it is sticky).  The primitive-centric kernel derives
+// every round's fixed-point scale from the packets of THAT round, so one outlier pixel costs resolution only where it is.
+// (2) Undo what an earlier backward over the same forward left in the hand-off buffer (retain_graph / several losses):
+// the "handed over" bit of the counters and flag.
 __global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict__ g4, int N, int H, int W, int tiles_x,
                                                         int tiles_y, uint32_t *__restrict__ pmax,
                                                         uint32_t *__restrict__ counts, size_t ncounts,
@@ -1586,11 +1614,11 @@ __global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncounts; i += stride) {
         const uint32_t c = counts[i];
-        if (c & kCountDead) counts[i] = c & ~kCountDead;
+        if (c & ~kCountMask) counts[i] = c & kCountMask;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t f = tail[0];
-        if (f & kFlagBwdHandoff) tail[0] = f & ~kFlagBwdHandoff;
+        if (f & (kFlagBwdHandoff | kFlagBwdPrecise)) tail[0] = f & ~(kFlagBwdHandoff | kFlagBwdPrecise);
     }
 }
 
@@ -1602,55 +1630,42 @@ __device__ __forceinline__ int fix_rn(float v) {
     return r;
 }
 
-// largest power of two s with B * s < 2^kFixHiBits (B finite, normal, > 0)
-__device__ __forceinline__ float fix_scale(float B) {
-    const int e = (int)((__float_as_uint(B) >> 23) & 0xffu) - 127;  // floor(log2 B)
-    return __uint_as_float((uint32_t)(127 + kFixHiBits - 1 - e) << 23);
-}
-
-// Value of one fixed-point accumulator pair.  `hi` holds sum(t >> 16); `lo` holds sum(t) modulo 2^32 (the full word is
-// added, no masking in the hot loop).  With r = sum(t & 0xffff) in [0, 2^16 * n), n <= 65536 samples between drains,
-// sum(t) = hi * 2^16 + r and r = (lo - (hi << 16)) mod 2^32 exactly.
-__device__ __forceinline__ float fix_value(int hi, uint32_t lo) {
-    const uint32_t r = lo - ((uint32_t)hi << 16);
-    return (float)hi * 65536.f + (float)r;
-}
-
-// TS > 0: the slab is TS^3 (compile-time strides: the 64 atomics and 8 reads of a sample share ONE address register and
+// TS > 0: the slab is TS^3 (compile-time strides: the 32 atomics and 8 reads of a sample share ONE address register and
 // use immediate offsets); TS == 0: any slab size, strides in registers.
 // WARP: the warp-field sampler (algo 1, primsampler.h:53-58,82-88): a second LDS slab (the warp grid) and a second set of
 // fixed-point accumulators (grad_warp); the template is sampled at warp(y) with zero padding (general strides only).
-template <bool FADE8, int TS, int PW, bool WARP = false>
-__global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const MarchParams p) {
+#ifndef MVP_BWD_OCC
+#define MVP_BWD_OCC 3  // waves per SIMD the register allocation aims at (timing experiments: 4 = at most 128 VGPRs)
+#endif
+// RESID: the two-pass instantiation (header, DYNAMIC RANGE): owns the primitives the plain one marked, nothing else.
+template <bool FADE8, int TS, int PW, bool WARP, bool RESID>
+__device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int block, float4 *smem4) {
     static_assert(!WARP || TS == 0, "the warp-field variant uses run-time slab dimensions");
     constexpr int kPrimWaves = PW, kPrimBlock = PW * 64;
     constexpr int kEntriesPerRound = prim_entries_per_round(PW), kQueueCap = prim_queue_cap(PW);
     const int TD = TS ? TS : p.TD, TH = TS ? TS : p.TH, TW = TS ? TS : p.TW;
-    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     const int V = TD * TH * TW;
     const int gH = TW, gD = TH * TW + kGradPadZ;  // gradient-array strides (words); x stride 1
     const int Vp = TD * gD;
     float4 *s_T = smem4;
-    int *s_hi = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar
-    uint32_t *s_lo = reinterpret_cast<uint32_t *>(s_hi + 4 * Vp);
-    // (whenever the per-slab sample count since the last drain nears 65536 the integer sums are flushed into
-    //  grad_template itself -- every voxel has one owner thread -- and restart from zero)
-    uint2 *s_q = reinterpret_cast<uint2 *>(s_lo + 4 * Vp);  // 8*Vp words past a 16-byte aligned base
+    int *s_acc = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar fixed-point sums
+    uint2 *s_q = reinterpret_cast<uint2 *>(s_acc + 4 * Vp);  // (Vp is even: 8-byte aligned)
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
-    // WARP: [warp grid as float4 (x,y,z,-)][3][VWp] hi, [3][VWp] lo -- behind everything else (16-byte aligned: the
+    uint16_t *s_perm = reinterpret_cast<uint16_t *>(s_bucket + kLenBuckets);  // pl_cap entries: list index by rank
+    uint32_t *s_gext = reinterpret_cast<uint32_t *>(s_red + 62);  // per round: bits(max), bits(min) of the queued rays' max |g|
+    // WARP: [warp grid as float4 (x,y,z,-)][3][VWp] fixed-point sums -- behind everything else (16-byte aligned: the
     // host sizes the part above as a multiple of 16 bytes)
     const int WD = WARP ? p.WD : 2, WH = WARP ? p.WH : 2, WW = WARP ? p.WW : 2;
     const int VW = WD * WH * WW, gHw = WW, gDw = WH * WW + kGradPadZ, VWp = WD * gDw;
     float4 *s_W = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem4) + p.prim_lds_base);
-    int *s_whi = reinterpret_cast<int *>(s_W + VW);
-    uint32_t *s_wlo = reinterpret_cast<uint32_t *>(s_whi + 3 * VWp);
+    int *s_wacc = reinterpret_cast<int *>(s_W + VW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const int K = p.K;
     int n, k;
-    if (!prim_of_block(p, blockIdx.x, n, k)) return;
+    if (!prim_of_block(p, block, n, k)) return;
     const size_t pk = (size_t)n * K + k;
     uint32_t *tail = p.pl_count + (size_t)p.N * K;  // [0] flags, [1] reserved, [2] bits(Rmax); then per-packet bits(max |g|)
     const uint32_t *pmax_n = tail + 3 + (size_t)n * p.tiles_x * p.tiles_y;
@@ -1661,7 +1676,10 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
     // either way).  The former order (counter -> branch -> slab -> barrier -> transform) cost two more dependent
     // global round trips per workgroup.
     const uint32_t flags = cload(tail);
-    const uint32_t cnt = cload(p.pl_count + pk);
+    // (the two-pass instantiation reads what the plain one, an earlier launch on this stream, wrote: a plain load)
+    const uint32_t cnt_raw = RESID ? (uint32_t)uni((int)p.pl_count[pk]) : cload(p.pl_count + pk);
+    if (RESID && (cnt_raw & (kCountPrecise | kCountDead)) != kCountPrecise) return;  // not marked (or handed over since)
+    const uint32_t cnt = cnt_raw & kCountMask;
     const float *qp = p.primpos + pk * 3, *qr = p.primrot + pk * 9, *qs = p.primscale + pk * 3;
     Rec q;  // SGPRs
     q.pos = mk3(cload(qp), cload(qp + 1), cload(qp + 2));
@@ -1681,83 +1699,82 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
 
-    // ---- stage the slab and its max |rgb|; bound of the upstream gradient over the packets on the list ----
-    float tmax = 0.f, amax = 0.f;  // amax (max |opacity|): only the warp-field bound needs it
-    uint32_t gbits = 0u;
+    // ---- stage the slab with its max |rgb| and max |opacity|; longest step range on the list ----
+    float tmax = 0.f, amax = 0.f;
+    uint32_t maxlen = 1u;  // longest packet step range on the list (a ray's own range is inside its packet's)
     if (!dead && cnt > 0u) {
-        for (uint32_t e = tid; e < cnt; e += kPrimBlock) gbits = max(gbits, pmax_n[list[e].x >> 9]);
+        for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
+            const uint32_t rg = list[e].y;
+            // (a ray with more than 127 steps in this box sends the primitive to the ray-centric kernel: phase 1)
+            maxlen = max(maxlen, min((rg >> 16) - (rg & 0xffffu) + 1u, 127u));
+        }
         if constexpr (WARP) {
             const float *Wg = p.warp + pk * (size_t)VW * 3;
             for (int v = tid; v < VW; v += kPrimBlock) s_W[v] = make_float4(Wg[v * 3], Wg[v * 3 + 1], Wg[v * 3 + 2], 0.f);
-            for (int v = tid; v < 3 * VWp; v += kPrimBlock) s_whi[v] = 0, s_wlo[v] = 0u;
+            for (int v = tid; v < 3 * VWp; v += kPrimBlock) s_wacc[v] = 0;
         }
         if (TS == 8) {
 #pragma unroll
             for (int i = 0; i < kVoxPerThread; ++i) {
                 if (tid + i * kPrimBlock < 512) s_T[tid + i * kPrimBlock] = tv[i];
                 tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(tv[i].x), fabsf(tv[i].y)), fabsf(tv[i].z)));
+                amax = fmaxf(amax, fabsf(tv[i].w));
             }
         } else {
             for (int v = tid; v < V; v += kPrimBlock) {
                 const float4 t = T4[v];
                 s_T[v] = t;
                 tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
-                if constexpr (WARP) amax = fmaxf(amax, fabsf(t.w));
+                amax = fmaxf(amax, fabsf(t.w));
             }
         }
-        // hi and lo are adjacent (8 * Vp words from a 16-byte aligned base): 16-byte stores.  The float drain target is
-        // NOT cleared here: it is written (not added to) by the first drain and ignored when there was none.
-        {
-            float4 *z4 = reinterpret_cast<float4 *>(s_hi);
-            const int nz4 = (8 * Vp) >> 2;
+        {  // clear the sums: 4 * Vp words from a 16-byte aligned base, 16-byte stores
+            float4 *z4 = reinterpret_cast<float4 *>(s_acc);
+            const int nz4 = (4 * Vp) >> 2;
             for (int v = tid; v < nz4; v += kPrimBlock) z4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int v = (nz4 << 2) + tid; v < 8 * Vp; v += kPrimBlock) s_hi[v] = 0;
+            for (int v = (nz4 << 2) + tid; v < 4 * Vp; v += kPrimBlock) s_acc[v] = 0;
         }
         tmax = wave_max(tmax);
-        gbits = (uint32_t)wave_max((int)gbits);
-        if (lane == 0) s_red[wave] = tmax, s_red[4 + wave] = __uint_as_float(gbits);
-        if constexpr (WARP) {
-            amax = wave_max(amax);
-            if (lane == 0) s_red[8 + wave] = amax;
-        }
+        amax = wave_max(amax);
+        maxlen = (uint32_t)wave_max((int)maxlen);
+        if (lane == 0) s_red[wave] = tmax, s_red[8 + wave] = amax, s_red[12 + wave] = __uint_as_float(maxlen);
     }
     __syncthreads();
-    float s_rgb = 0.f, s_a = 0.f, s_w = 0.f;
+    // What the bounds of a round's contributions are made of, besides the round's own max |grad_rayrgba| G_q (header):
+    //   colour:  |w_c * dLs.rgb| <= wrgb * G_q,  wrgb = wmax = min(1, Amax * dt) >= every |sample weight| (checked per sample)
+    //   opacity: |w_c * dLs.a|   <= fa * G_q,    fa = dt * (3 (Tmax + Rmax) + 1)        (fade <= 1)
+    //   WARP: a corner of the warp grid receives w_c * dL/dy1, |w_c| <= 1 and dL/dy1_x = (TW-1)/2 * sum over corners of
+    //         +-w_y w_z (value_c . dLs) with sum |w_y w_z| <= 2, |value_c . dLs| <= (3 Tmax wrgb + Amax fa) G_q
+    float wmax = 1.f, wrgb = 1.f, fa = 1.f, fw = 1.f;
     if (!dead && cnt > 0u) {
-        tmax = s_red[0], gbits = __float_as_uint(s_red[4]);
+        tmax = s_red[0], amax = s_red[8], maxlen = __float_as_uint(s_red[12]);
 #pragma unroll
         for (int w = 1; w < kPrimWaves; ++w)
-            tmax = fmaxf(tmax, s_red[w]), gbits = max(gbits, __float_as_uint(s_red[4 + w]));
-        if constexpr (WARP) {
-            amax = s_red[8];
-#pragma unroll
-            for (int w = 1; w < kPrimWaves; ++w) amax = fmaxf(amax, s_red[8 + w]);
-        }
-        const float G = gbits > 0x7f800000u ? INFINITY : __uint_as_float(gbits);  // NaN -> Inf -> handed over below
+            tmax = fmaxf(tmax, s_red[w]), amax = fmaxf(amax, s_red[8 + w]), maxlen = max(maxlen, __float_as_uint(s_red[12 + w]));
         const float Rmax = __uint_as_float(cload(tail + 2));
-        // |w_c * dLs.rgb| <= G (weight <= 1);  |w_c * dLs.a| <= dt * (3 (Tmax + Rmax) + 1) * G  (fade <= 1)
-        const float Brgb = G, Ba = p.stepsize * (3.f * (tmax + Rmax) + 1.f) * G;
-        // WARP: a corner of the warp grid receives w_c * dL/dy1, |w_c| <= 1 and dL/dy1_x = (TW-1)/2 * sum over corners of
-        // +-w_y w_z (value_c . dLs) with sum |w_y w_z| <= 2, |value_c . dLs| <= 3 Tmax G + Amax Ba
-        float Bw = 1.f;
-        if constexpr (WARP)
-            Bw = (float)(max(TD, max(TH, TW)) - 1) * (3.f * tmax * Brgb + amax * Ba);
-        if (G == 0.f) {
-            s_rgb = s_a = -1.f;  // all-zero upstream gradient on every listed packet: outputs are zero
-        } else if (!(Ba < 1.0e30f) || !(Brgb < 1.0e30f) || !(Brgb > 1.0e-30f) || !(Ba > 1.0e-30f) || !(Bw < 1.0e30f)) {
-            dead = true;  // hand over to the ray-centric kernel (launched after this one on the stream)
+        wmax = fminf(1.f, amax * p.stepsize * 1.0001f);
+        // (a fully transparent slab -- relu(alpha) = 0 everywhere -- has wmax = 0: its rgb contributions are exact zeros and
+        //  any scale serves; its opacity gradient is not zero)
+        wrgb = fmaxf(wmax, 9.5367431640625e-07f);
+        fa = p.stepsize * (3.f * (tmax + Rmax) + 1.f);
+        if constexpr (WARP) fw = (float)(max(TD, max(TH, TW)) - 1) * (3.f * tmax * wrgb + amax * fa);
+        if (!(fa < 1.0e30f) || !(fw < 1.0e30f)) {  // non-finite slab / raysat: the ray-centric kernel's case
+            dead = true;
             if (tid == 0) {
                 atomicOr(p.pl_count + pk, kCountDead);
                 raise_flag(tail, kFlagBwdHandoff);
             }
-        } else {
-            s_rgb = fix_scale(Brgb) * 65536.f;  // value -> int(value * s): 16 fractional bits
-            s_a = fix_scale(Ba) * 65536.f;
-            if constexpr (WARP) s_w = fix_scale(fmaxf(Bw, 1.0e-30f)) * 65536.f;
         }
     }
+    // (workgroup-uniform values computed from LDS reads: moved to SGPRs, the march's VGPR budget has no room for them)
+    wmax = uni(wmax), wrgb = uni(wrgb), fa = uni(fa), maxlen = (uint32_t)uni((int)maxlen);
+    if constexpr (WARP) fw = uni(fw);
+    // list entries per round: all the workgroup can look at (kEntriesPerRound), fewer when the packets' step ranges are long
+    // (64 lanes x range x entries <= 2^kRoundBudgetLog2 keeps a round's sample count, hence its scale exponent c, small)
+    const uint32_t epr = min((uint32_t)kEntriesPerRound, max(1u, (1u << kRoundBudgetLog2) / (64u * maxlen)));
+    const bool multi = cnt > epr;  // more than one round: walk the entries in ascending key order (see the header)
     __syncthreads();  // s_red is reused below
-    if (cnt == 0u || dead || s_rgb < 0.f) {  // this launch doubles as the zero-fill of the gradient buffers
+    if (cnt == 0u || dead) {  // this launch doubles as the zero-fill of the gradient buffers
         if constexpr (WARP) {
             float *gW = p.grad_warp + pk * (size_t)VW * 3;
             for (int v = tid; v < VW * 3; v += kPrimBlock) gW[v] = 0.f;
@@ -1785,12 +1802,73 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
     uint32_t ex_groups = 0u, ex_addr = 0u, ex_lanes = 0u, ex_bank[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
 #endif
     if (tid == 0) s_qn[2] = 0u;
-    bool wbad = false;      // some sample weight was outside [-1, 1]: the integer sums cannot be trusted
-    uint32_t pending = 0u;  // samples accumulated into the integer arrays since the last drain (workgroup-uniform)
-    bool drained = false;   // the float drain target holds data (workgroup-uniform)
-    for (uint32_t ebase = 0; ebase < cnt; ebase += kEntriesPerRound) {
+    if (multi) {
+        // rank of every entry among the list's keys ((packet << 9) | slot: one entry per packet, all different); the key
+        // stream is wave-uniform -> scalar loads, four entries (32 bytes; pl_cap is a multiple of 4) at a time
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: HIP's uint4 class has no
+        typedef const __attribute__((address_space(4))) u32x4 *cu4;   //  constructor from another address space)
+        const cu4 l4 = reinterpret_cast<cu4>(reinterpret_cast<uintptr_t>(list));
+        for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
+            const uint32_t key = list[e].x;
+            uint32_t rank = 0u;
+            for (uint32_t j = 0; j < cnt; j += 4u) {
+                const u32x4 a = l4[j >> 1], b = l4[(j >> 1) + 1];
+                rank += (a.x < key ? 1u : 0u) + ((j + 1u < cnt && a.z < key) ? 1u : 0u) +
+                        ((j + 2u < cnt && b.x < key) ? 1u : 0u) + ((j + 3u < cnt && b.z < key) ? 1u : 0u);
+            }
+            s_perm[rank] = (uint16_t)e;
+        }
+    }
+    bool wbad = false;      // some sample weight was outside the bound: the integer sums cannot be trusted
+    bool drained = false;   // grad_template holds the flushed sums of earlier rounds / passes (workgroup-uniform)
+    float s_rgb = 1.f, s_a = 1.f, s_w = 1.f;  // this round's scales (workgroup-uniform)
+    float cur_mul = 1.f;    // ... times this in the pass being marched (1, or the residual multiplier of pass B)
+    // More sums follow (another pass, another round): move the integer sums, divided by their scale, into grad_template
+    // itself and restart from zero.  Every voxel is owned by one thread, here and at the end, so the partial sums need
+    // no atomics and no second LDS array: written by the first flush, added to by later ones.
+    auto flush_sums = [&](float i_rgb, float i_a, float i_w) {
+        size_t pkd = pk;
+        int td = tid;
+        asm volatile("; flush addresses are made here" : "+s"(pkd), "+v"(td));
+        float4 *gd = reinterpret_cast<float4 *>(p.grad_tplate) + pkd * (size_t)V;
+        for (int v = td; v < V; v += kPrimBlock) {
+            const int z = v / sD, rem = v - z * sD;
+            const int gv = z * gD + rem;
+            float4 g;
+            g.x = (float)s_acc[gv] * i_rgb;
+            g.y = (float)s_acc[Vp + gv] * i_rgb;
+            g.z = (float)s_acc[2 * Vp + gv] * i_rgb;
+            g.w = (float)s_acc[3 * Vp + gv] * i_a;
+            if (drained) {
+                const float4 o_ = gd[v];
+                g.x += o_.x, g.y += o_.y, g.z += o_.z, g.w += o_.w;
+            }
+            gd[v] = g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_acc[c * Vp + gv] = 0;
+        }
+        if constexpr (WARP) {
+            float *gWd = p.grad_warp + pkd * (size_t)VW * 3;
+            const int sDw = WH * WW;
+            for (int v = td; v < VW; v += kPrimBlock) {
+                const int z = v / sDw, rem = v - z * sDw;
+                const int gv = z * gDw + rem;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float g = (float)s_wacc[j * VWp + gv] * i_w;
+                    if (drained) g += gWd[v * 3 + j];
+                    gWd[v * 3 + j] = g;
+                    s_wacc[j * VWp + gv] = 0;
+                }
+            }
+        }
+        drained = true;
+        __syncthreads();
+    };
+    bool pass_b = false;  // this iteration re-marches the round it has just marched, for the residuals (workgroup-uniform)
+    for (uint32_t ebase = 0; ebase < cnt;) {
         if (tid < kLenBuckets) s_bucket[tid] = 0u;
-        if (tid == 0) s_qn[1] = 0u;
+        if (tid == 0) s_qn[1] = 0u, s_gext[0] = 0u, s_gext[1] = 0x7fffffffu;
         __syncthreads();
         // The transform is block-uniform and lives in SGPRs.  Made opaque once per round, so that packed-math operand
         // pairs built from it are re-made here (a v_mov each) instead of being carried, spilled, across the march.
@@ -1802,12 +1880,13 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
         // Each wave owns up to kEntriesPerWave entries of the round; a live ray takes a ticket in the bucket of its step count
         // (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the
         // 64 rays a wave marches together have (nearly) the same number of steps.
-        const uint32_t eend = min(cnt, ebase + (uint32_t)kEntriesPerRound);
+        const uint32_t eend = min(cnt, ebase + epr);
         uint2 item[kEntriesPerWave];  // {ray index inside the image | list slot << 23, first step | steps << 16}
         uint32_t ticket[kEntriesPerWave];
         bool live2[kEntriesPerWave];
         bool toolong = false;
         uint32_t mylen = 0u;
+        uint32_t gq_hi = 0u;  // bits of the largest max |grad_rayrgba| over the packets this wave queued rays of (wave-uniform)
 #pragma unroll
         for (int u = 0; u < kEntriesPerWave; ++u) {
             const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
@@ -1815,7 +1894,8 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
             ticket[u] = 0u;
             item[u] = make_uint2(0u, 0u);
             if (e < eend) {
-                const uint32_t *lw = reinterpret_cast<const uint32_t *>(list + e);  // wave-uniform: scalar loads
+                const uint32_t le = multi ? (uint32_t)uni((int)s_perm[e]) : e;
+                const uint32_t *lw = reinterpret_cast<const uint32_t *>(list + le);  // wave-uniform: scalar loads
                 const uint2 ent = make_uint2(cload(lw), cload(lw + 1));
                 const int tidx = (int)(ent.x >> 9);
                 const uint32_t slot = ent.x & 511u;
@@ -1843,6 +1923,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                         shi = min(h0, ehi);
                     }
                 }
+                if (__ballot(slo <= shi) != 0ull) gq_hi = max(gq_hi, cload(pmax_n + tidx));
                 if (slo <= shi) {
                     // at most 127 steps per queued item (the len field and the buckets assume short crossings); a box
                     // that is deeper than that along some ray is handed to the ray-centric kernel (flagged below)
@@ -1856,16 +1937,33 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
             }
         }
         if (__ballot(toolong) != 0ull && lane == 0) atomicOr(s_qn + 2, 1u);
-        {  // exact number of samples this round can add: one LDS atomic per wave (values < 2^24: exact in float)
+        {  // exact number of samples this round can add, and the bound of its upstream gradients: LDS atomics by one lane
+           // per wave (sample counts < 2^24: exact in float)
             const float wl = wave_sum((float)mylen);
-            if (lane == 0 && wl > 0.f) atomicAdd(s_qn + 1, (uint32_t)wl);
+            if (lane == 0 && wl > 0.f) {
+                atomicAdd(s_qn + 1, (uint32_t)wl);
+                atomicMax(s_gext, gq_hi);
+            }
         }
         __syncthreads();
-        // a ray crosses this box over more than 127 steps, a sample weight left [-1, 1] in an earlier round (signed
-        // opacity), or the round alone would add more samples than the integer accumulators can take between two
-        // drains: not this kernel's case
-        // (WARP: no mid-way drain of the second accumulator set -- such a primitive is handed over as a whole)
-        if (s_qn[2] != 0u || s_qn[1] > kFixMaxSamples || (WARP && pending + s_qn[1] > kFixMaxSamples)) {
+        // ---------------- this round's bound and scales (header) ----------------
+        const uint32_t round_samples = (uint32_t)uni((int)s_qn[1]);  // exact; <= kQueueCap * 127 < 2^17
+        const uint32_t gq_bits = (uint32_t)uni((int)s_gext[0]);
+        const float Gq = __uint_as_float(gq_bits);
+        bool bad_bound = false;
+        float res_mul = 1.f;  // pass B: residuals (|r| <= 1/2) times this
+        s_rgb = s_a = s_w = 1.f;
+        if (round_samples > 0u && gq_bits != 0u) {  // (G_q = 0: every marched ray is skipped, scales are irrelevant)
+            const float Brgb = wrgb * Gq, Ba = fa * Gq, Bw = WARP ? fw * Gq : 1.f;
+            bad_bound = gq_bits >= 0x7f800000u || !(Brgb < 1.0e30f) || !(Ba < 1.0e30f) || !(Brgb > 1.0e-30f) ||
+                        !(Ba > 1.0e-30f) || !(Bw < 1.0e30f);
+            res_mul = kFixRange / (float)round_samples;
+            s_rgb = uni(res_mul / Brgb), s_a = uni(res_mul / Ba);
+            if constexpr (WARP) s_w = uni(res_mul / fmaxf(Bw, 1.0e-30f));
+        }
+        // a ray crosses this box over more than 127 steps, a sample weight left its bound in an earlier round (signed
+        // opacity), or the upstream gradient / the slab is not finite: not this kernel's case
+        if (s_qn[2] != 0u || bad_bound) {
             if (tid == 0) {
                 atomicOr(p.pl_count + pk, kCountDead);
                 raise_flag(tail, kFlagBwdHandoff);
@@ -1903,42 +2001,13 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
         for (int u = 0; u < kEntriesPerWave; ++u)
             if (live2[u]) s_q[s_bucket[min((int)(item[u].y >> 16), kLenBuckets) - 1] + ticket[u]] = item[u];
         __syncthreads();
-        // ---------------- drain the integer accumulators before they could overflow ----------------
-        const uint32_t round_samples = s_qn[1];
-        if (pending + round_samples > kFixMaxSamples) {
-            // (rare: > 65536 samples on one primitive.)  Every voxel is owned by one thread, here and at the end, so the
-            // partial sums can live in grad_template itself: written by the first drain, added to by later ones.
-            const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
-            size_t pkd = pk;
-            int td = tid;
-            asm volatile("; drain addresses are made here" : "+s"(pkd), "+v"(td));
-            float4 *gd = reinterpret_cast<float4 *>(p.grad_tplate) + pkd * (size_t)V;
-            for (int v = td; v < V; v += kPrimBlock) {
-                const int z = v / sD, rem = v - z * sD;
-                const int gv = z * gD + rem;
-                float4 g;
-                g.x = fix_value(s_hi[gv], s_lo[gv]) * i_rgb;
-                g.y = fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
-                g.z = fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
-                g.w = fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
-                if (drained) {
-                    const float4 o_ = gd[v];
-                    g.x += o_.x, g.y += o_.y, g.z += o_.z, g.w += o_.w;
-                }
-                gd[v] = g;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) s_hi[c * Vp + gv] = 0, s_lo[c * Vp + gv] = 0u;
-            }
-            drained = true;
-            pending = 0u;
-            __syncthreads();
-        }
-        pending += round_samples;  // <= kFixMaxSamples by the guard above
         // ---------------- phase 2: the queued rays in chunks of 64, dealt to the 4 waves ----------------
         // Full chunks, even when that leaves waves without work: the longest ray sets the round's critical path either
         // way, and 2 waves x 64 lanes issue half the instructions (VALU and LDS atomics) of 4 waves x 32 lanes.
         const int nq = (int)*s_qn;
         const int per = kWave;
+        cur_mul = pass_b ? res_mul : 1.f;
+        uint32_t gq_lo = 0x7fffffffu;  // bits of the smallest max |grad_rayrgba| over the rays this lane marches
         for (int qb = wave * per; qb < nq; qb += kPrimWaves * per) {
             // queue neighbours are usually neighbouring pixels, i.e. rays in the same slab cell: put them in DIFFERENT
             // 32-lane halves so that their LDS atomics to the same address do not meet in one pass
@@ -1946,7 +2015,8 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
             const bool have = ql < per && qb + ql < nq;
             const uint2 it = have ? s_q[qb + ql] : make_uint2(0u, 0u);
             const uint32_t r = it.x & 0x7fffffu;  // index inside image n
-            const int slo = (int)(it.y & 0xffffu), len = have ? (int)(it.y >> 16) : 0;
+            const int slo = (int)(it.y & 0xffffu);
+            int len = have ? (int)(it.y >> 16) : 0;
             const uint32_t slot = it.x >> 23;
             f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
             float tmin = 0.f;
@@ -1960,6 +2030,11 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                 const float4 g4 = *at_bytes<float4>(grad_n, r * 16u);
                 dL3 = mk3(g4.x, g4.y, g4.z);
                 dLw = g4.w;
+                // bits of this ray's max |upstream gradient| (non-negative floats order like uints).  Zero: the ray adds
+                // exact zeros to every gradient -- not marched
+                const uint32_t gb = max(max(__float_as_uint(g4.x) & 0x7fffffffu, __float_as_uint(g4.y) & 0x7fffffffu),
+                                        max(__float_as_uint(g4.z) & 0x7fffffffu, __float_as_uint(g4.w) & 0x7fffffffu));
+                if (gb == 0u) len = 0; else gq_lo = min(gq_lo, gb);
                 rsat = ld3(at_bytes<float>(raysat_n, r * 12u));
                 const uint4 aux = *at_bytes<uint4>(aux_n, r * 16u);
                 satkey = aux.x;
@@ -2077,7 +2152,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                         const float alpha = v.w * fade;
                         const bool issat = key == satkey;
                         const float weight = issat ? (1.f - wbefore) : alpha * dt;
-                        wbad = wbad || !(fabsf(weight) <= 1.0f);
+                        wbad = wbad || !(fabsf(weight) <= wmax);
                         float4 dLs;
                         dLs.x = weight * dL3.x;
                         dLs.y = weight * dL3.y;
@@ -2089,11 +2164,11 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                         const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
                         f3 gy = ypow * gf;
                         dLs.w *= fade;
-#define MVP_FIXW(HI_, LO_, IDX_, VAL_)                              \
-    {                                                               \
-        const int t_ = fix_rn(VAL_);                                \
-        atomicAdd((HI_) + (IDX_), t_ >> 16);                        \
-        atomicAdd((LO_) + (IDX_), (uint32_t)t_);                    \
+#define MVP_FIXW(ACC_, IDX_, VAL_)                                                                  \
+    {                                                                                               \
+        const float x_ = (VAL_);                                                                    \
+        const int t_ = fix_rn(x_);                                                                  \
+        atomicAdd((ACC_) + (IDX_), (!RESID || !pass_b) ? t_ : fix_rn((x_ - (float)t_) * res_mul));  \
     }
                         f3 gi1 = mk3(0.f, 0.f, 0.f);
 #pragma unroll
@@ -2103,10 +2178,10 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                             if (tri_inb(tt, c, TD, TH, TW, vox, w)) {
                                 const float4 qv = s_T[vox];
                                 const int gv = (tt.z0 + (c >> 2)) * gD + (tt.y0 + ((c >> 1) & 1)) * gH + tt.x0 + (c & 1);
-                                MVP_FIXW(s_hi, s_lo, gv, w * dLs.x * s_rgb)
-                                MVP_FIXW(s_hi, s_lo, Vp + gv, w * dLs.y * s_rgb)
-                                MVP_FIXW(s_hi, s_lo, 2 * Vp + gv, w * dLs.z * s_rgb)
-                                MVP_FIXW(s_hi, s_lo, 3 * Vp + gv, w * dLs.w * s_a)
+                                MVP_FIXW(s_acc, gv, w * dLs.x * s_rgb)
+                                MVP_FIXW(s_acc, Vp + gv, w * dLs.y * s_rgb)
+                                MVP_FIXW(s_acc, 2 * Vp + gv, w * dLs.z * s_rgb)
+                                MVP_FIXW(s_acc, 3 * Vp + gv, w * dLs.w * s_a)
                                 tri_posgrad_acc(tt, c, qv.x * dLs.x + qv.y * dLs.y + qv.z * dLs.z + qv.w * dLs.w, gi1);
                             }
                         }
@@ -2119,9 +2194,9 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                             if (tri_inb(tw, c, WD, WH, WW, vox, w)) {
                                 const float4 qw = s_W[vox];
                                 const int gv = (tw.z0 + (c >> 2)) * gDw + (tw.y0 + ((c >> 1) & 1)) * gHw + tw.x0 + (c & 1);
-                                MVP_FIXW(s_whi, s_wlo, gv, w * g1.x * s_w)
-                                MVP_FIXW(s_whi, s_wlo, VWp + gv, w * g1.y * s_w)
-                                MVP_FIXW(s_whi, s_wlo, 2 * VWp + gv, w * g1.z * s_w)
+                                MVP_FIXW(s_wacc, gv, w * g1.x * s_w)
+                                MVP_FIXW(s_wacc, VWp + gv, w * g1.y * s_w)
+                                MVP_FIXW(s_wacc, 2 * VWp + gv, w * g1.z * s_w)
                                 tri_posgrad_acc(tw, c, qw.x * g1.x + qw.y * g1.y + qw.z * g1.z, gi0);
                             }
                         }
@@ -2185,7 +2260,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                     const float alpha = v.w * fade;
                     const bool issat = key == satkey;
                     const float weight = issat ? (1.f - wbefore) : alpha * dt;
-                    wbad = wbad || !(fabsf(weight) <= 1.0f);  // outside the fixed-point bound (signed opacity) or NaN
+                    wbad = wbad || !(fabsf(weight) <= wmax);  // outside the fixed-point bound (signed opacity) or NaN
                     float4 dLs;
                     dLs.x = weight * dL3.x;
                     dLs.y = weight * dL3.y;
@@ -2228,50 +2303,55 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
 #else
                         const int gb = z0 * gD + y0 * gH + x0;
 #endif
-                        int *Hp = s_hi + gb;
-                        uint32_t *Lp = s_lo + gb;
+                        int *Ap = s_acc + gb;
 #if MVP_EXP == 2
-#define MVP_FIX1(OFF_, VAL_)                                        \
-    {                                                               \
-        const int t_ = fix_rn(VAL_);                                \
-        exp_sink ^= (t_ >> 16) + (int)(OFF_);                       \
-    }
+#define MVP_FIX1(OFF_, VAL_) exp_sink ^= fix_rn(VAL_) + (int)(OFF_);
+#define MVP_FIX1B(OFF_, VAL_) MVP_FIX1(OFF_, VAL_)
 #else
-#define MVP_FIX1(OFF_, VAL_)                                        \
-    {                                                               \
-        const int t_ = fix_rn(VAL_);                                \
-        atomicAdd(Hp + (OFF_), t_ >> 16);                           \
-        atomicAdd(Lp + (OFF_), (uint32_t)t_);                       \
+#define MVP_FIX1(OFF_, VAL_) atomicAdd(Ap + (OFF_), fix_rn(VAL_));
+// pass B of a two-pass round: what pass A rounded away, x - rn(x) (exact in fp32), at res_mul units per unit
+#define MVP_FIX1B(OFF_, VAL_)                                                   \
+    {                                                                           \
+        const float x_ = (VAL_);                                                \
+        atomicAdd(Ap + (OFF_), fix_rn((x_ - (float)fix_rn(x_)) * res_mul));     \
     }
 #endif
-#define MVP_LSCATTER(OFF_, WGT_)                                    \
+#define MVP_LSCATTER(FIX_, OFF_, WGT_)                              \
     {                                                               \
         const v2f a_ = qxy * (WGT_), b_ = qzw * (WGT_);             \
-        MVP_FIX1((OFF_), a_.x)                                      \
-        MVP_FIX1((OFF_) + Vp, a_.y)                                 \
-        MVP_FIX1((OFF_) + 2 * Vp, b_.x)                             \
-        MVP_FIX1((OFF_) + 3 * Vp, b_.y)                             \
+        FIX_((OFF_), a_.x)                                          \
+        FIX_((OFF_) + Vp, a_.y)                                     \
+        FIX_((OFF_) + 2 * Vp, b_.x)                                 \
+        FIX_((OFF_) + 3 * Vp, b_.y)                                 \
     }
-                        MVP_LSCATTER(0, w000)
-                        MVP_LSCATTER(1, w001)
-                        MVP_LSCATTER(gH, w010)
-                        MVP_LSCATTER(gH + 1, w011)
-                        MVP_LSCATTER(gD, w100)
-                        MVP_LSCATTER(gD + 1, w101)
-                        MVP_LSCATTER(gD + gH, w110)
-                        MVP_LSCATTER(gD + gH + 1, w111)
+#define MVP_LSCATTER8(FIX_)                                         \
+    MVP_LSCATTER(FIX_, 0, w000)                                     \
+    MVP_LSCATTER(FIX_, 1, w001)                                     \
+    MVP_LSCATTER(FIX_, gH, w010)                                    \
+    MVP_LSCATTER(FIX_, gH + 1, w011)                                \
+    MVP_LSCATTER(FIX_, gD, w100)                                    \
+    MVP_LSCATTER(FIX_, gD + 1, w101)                                \
+    MVP_LSCATTER(FIX_, gD + gH, w110)                               \
+    MVP_LSCATTER(FIX_, gD + gH + 1, w111)
+                        if (!RESID || !pass_b) {  // (workgroup-uniform; the residual scatter exists in RESID only)
+                            MVP_LSCATTER8(MVP_FIX1)
+                        } else {
+                            MVP_LSCATTER8(MVP_FIX1B)
+                        }
+#undef MVP_LSCATTER8
 #undef MVP_LSCATTER
+#undef MVP_FIX1B
 #undef MVP_FIX1
                     }
 #if MVP_EXP == 2
-                    if (exp_sink == 0x12345678) s_hi[gD] = exp_sink;
+                    if (exp_sink == 0x12345678) s_acc[gD] = exp_sink;
 #endif
                     // xmt = (o - pos) + d * t is affine in t along this ray: keep sum(gy) and sum(t * gy) only
                     ra0 += gy.x, ra1 += gy.y, ra2 += gy.z;
                     rb0 = fmaf(t, gy.x, rb0), rb1 = fmaf(t, gy.y, rb1), rb2 = fmaf(t, gy.z, rb2);
                 }
             }
-            {  // sum xmt_i * gy_j over this ray's samples = (o_i - pos_i) * sum(gy_j) + d_i * sum(t * gy_j)
+            if (!pass_b) {  // sum xmt_i * gy_j over this ray's samples = (o_i - pos_i) * sum(gy_j) + d_i * sum(t * gy_j)
                 const f3 om = o - q.pos;
                 a0 += ra0, a1 += ra1, a2 += ra2;
                 c00 += om.x * ra0 + d.x * rb0, c01 += om.x * ra1 + d.x * rb1, c02 += om.x * ra2 + d.x * rb2;
@@ -2279,7 +2359,34 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
                 c20 += om.z * ra0 + d.z * rb0, c21 += om.z * ra1 + d.z * rb1, c22 += om.z * ra2 + d.z * rb2;
             }
         }
+        {
+            const uint32_t wlo = (uint32_t)wave_min((int)gq_lo);  // (bit patterns < 2^31: signed order)
+            if (lane == 0) atomicMin(s_gext + 1, wlo);
+        }
         __syncthreads();  // the queue is rewritten by the next round
+        if constexpr (RESID) {
+            if (!pass_b && round_samples > 0u) {
+                // pass A's sums leave, and the SAME round is marched again -- phase 1 included, it is deterministic --
+                // accumulating the residuals pass A rounded away
+                flush_sums(1.0f / s_rgb, 1.0f / s_a, 1.0f / s_w);
+                pass_b = true;
+                continue;
+            }
+        } else if (__uint_as_float((uint32_t)uni((int)s_gext[1])) * kTwoPassRatio < Gq) {
+            // (rare: header, DYNAMIC RANGE) the rays marched here are more than 256x below the round's bound: the two-pass
+            // instantiation, launched behind this kernel, owns the primitive and overwrites every output
+            if (tid == 0) {
+                atomicOr(p.pl_count + pk, kCountPrecise);
+                raise_flag(p.pl_count + (size_t)p.N * K, kFlagBwdPrecise);
+            }
+            return;
+        }
+        if (ebase + epr < cnt && round_samples > 0u) {  // more rounds follow
+            const float im = 1.0f / cur_mul;
+            flush_sums(im / s_rgb, im / s_a, im / s_w);
+        }
+        pass_b = false;
+        ebase += epr;
     }
 #if MVP_EXP == 4
     if (p.diag && lane == 0) {
@@ -2323,17 +2430,17 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
         if (tl < 3) p.grad_primpos[pkl * 3 + tl] = 0.f;
         return;
     }
-    {  // the slab gradient, written exactly once: (hi * 2^16 + lo) / scale
-        const float i_rgb = 1.0f / s_rgb, i_a = 1.0f / s_a;
+    {  // the slab gradient, written exactly once: sum / scale (of the last round's last pass)
+        const float i_rgb = 1.0f / (s_rgb * cur_mul), i_a = 1.0f / (s_a * cur_mul);
         for (int v = tl; v < V; v += kPrimBlock) {
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
-            g.x = fix_value(s_hi[gv], s_lo[gv]) * i_rgb;
-            g.y = fix_value(s_hi[Vp + gv], s_lo[Vp + gv]) * i_rgb;
-            g.z = fix_value(s_hi[2 * Vp + gv], s_lo[2 * Vp + gv]) * i_rgb;
-            g.w = fix_value(s_hi[3 * Vp + gv], s_lo[3 * Vp + gv]) * i_a;
-            if (drained) {  // (workgroup-uniform) earlier drains sit in grad_template already; same owner thread
+            g.x = (float)s_acc[gv] * i_rgb;
+            g.y = (float)s_acc[Vp + gv] * i_rgb;
+            g.z = (float)s_acc[2 * Vp + gv] * i_rgb;
+            g.w = (float)s_acc[3 * Vp + gv] * i_a;
+            if (drained) {  // (workgroup-uniform) earlier flushes sit in grad_template already; same owner thread
                 const float4 o_ = gT4l[v];
                 g.x = o_.x + g.x, g.y = o_.y + g.y, g.z = o_.z + g.z, g.w = o_.w + g.w;
             }
@@ -2341,14 +2448,18 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
         }
     }
     if constexpr (WARP) {  // grad_warp, written exactly once
-        const float i_w = 1.0f / s_w;
+        const float i_w = 1.0f / (s_w * cur_mul);
         float *gW = p.grad_warp + pkl * (size_t)VW * 3;
         const int sDw = WH * WW;
         for (int v = tl; v < VW; v += kPrimBlock) {
             const int z = v / sDw, rem = v - z * sDw;
             const int gv = z * gDw + rem;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) gW[v * 3 + j] = fix_value(s_whi[j * VWp + gv], s_wlo[j * VWp + gv]) * i_w;
+            for (int j = 0; j < 3; ++j) {
+                float g = (float)s_wacc[j * VWp + gv] * i_w;
+                if (drained) g += gW[v * 3 + j];
+                gW[v * 3 + j] = g;
+            }
         }
     }
     if (tl < 12) {
@@ -2371,6 +2482,25 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : 3) void bwd_prim_kernel(const M
             p.grad_primpos[pkl * 3 + ii] =
                 -(Rg[ii * 3 + 0] * sg[0] * A[0] + Rg[ii * 3 + 1] * sg[1] * A[1] + Rg[ii * 3 + 2] * sg[2] * A[2]);
         }
+    }
+}
+
+// One workgroup per (image, primitive): the grid of prim_of_block.
+template <bool FADE8, int TS, int PW, bool WARP = false>
+__global__ __launch_bounds__(PW * 64, WARP ? 2 : MVP_BWD_OCC) void bwd_prim_kernel(const MarchParams p) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    bwd_prim_body<FADE8, TS, PW, WARP, false>(p, (int)blockIdx.x, smem4);
+}
+
+// The two-pass instantiation (general slab strides, 2 waves): a small persistent grid that walks the same block -> primitive
+// map and works only on the primitives the kernel above marked; returns at once when it marked none.
+template <bool FADE8, bool WARP>
+__global__ __launch_bounds__(128, 2) void bwd_prim_precise_kernel(const MarchParams p, const int total_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    if ((p.pl_count[(size_t)p.N * p.K] & kFlagBwdPrecise) == 0u) return;
+    for (int b = (int)blockIdx.x; b < total_blocks; b += (int)gridDim.x) {
+        bwd_prim_body<FADE8, 0, 2, WARP, true>(p, b, smem4);
+        __syncthreads();  // (the next primitive restages the LDS this one's last readers may still be in)
     }
 }
 
@@ -2444,7 +2574,7 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
     }
     if (p.K > 0 && (!p.nodeaabb || !p.primpos || !p.primrot || !p.primscale || !p.tplate)) return MVP_ERR_BADARG;
     if (!aligned16(p.tplate) || (p.tminmax && !aligned16(p.tminmax)) || !aligned16(p.nodeaabb)) return MVP_ERR_BADARG;
-    if (p.pl_cap < 0) return MVP_ERR_BADARG;
+    if (p.pl_cap < 0 || (p.pl_cap & 3)) return MVP_ERR_BADARG;  // (lists are read four entries = 32 bytes at a time)
     if (p.rayaux && !aligned16(p.rayaux)) return MVP_ERR_BADARG;
     if (p.pl_list && !aligned16(p.pl_list)) return MVP_ERR_BADARG;
     const int rc_grid = setup_block_map(p);
@@ -2594,15 +2724,17 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     const bool norays = (long long)N * H * W == 0;
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
     const size_t Vp = (size_t)TD * ((size_t)TH * TW + kGradPadZ);
-    // float4 slab + 2 x [4][Vp] int32 + ray queue + reduce area (+ queue tail)
+    // float4 slab + [4][Vp] int32 + ray queue + reduce area (+ queue tail)
     // 2 or 3 waves per workgroup by the work a primitive has: ray packets per primitive (see the note at kEntriesPerWave)
     const int pw = ((long long)p.tiles_x * p.tiles_y * 4 > 5ll * K) ? 3 : 2;
-    size_t lds = V * 16 + Vp * 32 + (size_t)prim_queue_cap(pw) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4;
-    if (warp) {  // + the warp grid (float4 per node) and its 2 x [3][VWp] accumulators
+    // + list indices by rank (2 bytes per list slot; used by primitives whose list needs more than one round)
+    size_t lds = V * 16 + Vp * 16 + (size_t)prim_queue_cap(pw) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4 +
+                 (((size_t)(primlist_cap > 0 ? primlist_cap : 0) * 2 + 15) & ~(size_t)15);
+    if (warp) {  // + the warp grid (float4 per node) and its [3][VWp] accumulators
         lds = (lds + 15) & ~(size_t)15;
         p.prim_lds_base = (int)lds;
         const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + kGradPadZ);
-        lds += VW * 16 + VWp * 24;
+        lds += VW * 16 + VWp * 12;
     }
 #ifdef MVP_DEBUG_HOOKS
     if (const char *e = getenv("MVP_DEBUG_LDS_PAD")) lds += (size_t)atoi(e);  // occupancy experiments: fewer workgroups per CU
@@ -2663,6 +2795,29 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
 #undef MVP_LAUNCH_PRIMW
         rc = launch_status();
         if (rc != MVP_OK) return rc;
+        {  // the two-pass instantiation for the primitives that kernel marked (heavy-tailed upstream gradients); exits at
+           // once otherwise.  Same LDS layout with 2 waves per workgroup.
+            size_t lds2 = V * 16 + Vp * 16 + (size_t)prim_queue_cap(2) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4 +
+                          (((size_t)primlist_cap * 2 + 15) & ~(size_t)15);
+            MarchParams p2 = p;
+            if (warp) {
+                lds2 = (lds2 + 15) & ~(size_t)15;
+                p2.prim_lds_base = (int)lds2;
+                const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + kGradPadZ);
+                lds2 += VW * 16 + VWp * 12;
+            }
+            const dim3 g2((unsigned)(pb < 2048 ? pb : 2048)), b2(128);
+            if (warp && fade8)
+                hipLaunchKernelGGL((bwd_prim_precise_kernel<true, true>), g2, b2, lds2, st, p2, (int)pb);
+            else if (warp)
+                hipLaunchKernelGGL((bwd_prim_precise_kernel<false, true>), g2, b2, lds2, st, p2, (int)pb);
+            else if (fade8)
+                hipLaunchKernelGGL((bwd_prim_precise_kernel<true, false>), g2, b2, lds2, st, p2, (int)pb);
+            else
+                hipLaunchKernelGGL((bwd_prim_precise_kernel<false, false>), g2, b2, lds2, st, p2, (int)pb);
+            rc = launch_status();
+            if (rc != MVP_OK) return rc;
+        }
         p.fallback_all = 0;
     }
     // ray-centric kernel: everything (fallback_all) or only what the forward flagged; exits at once when no flag

@@ -88,8 +88,9 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  *                   filled: packets per primitive; a flags word; a reserved word; bits(max |raysat|).  The rest is
  *                   scratch of the BACKWARD (per 8x8 ray packet: bits(max |grad_rayrgba|), rewritten by every call).
  *                   The backward may be called several times over one forward (retain_graph): what it marks in
- *                   this buffer (counter bit 31, flag bit 2) it clears again at the start of the next call.
- *   primlist        [N*K, primlist_cap, 2] uint32: per primitive the (packet, list slot, step range) records
+ *                   this buffer (counter bits 30-31, flag bits 2-3) it clears again at the start of the next call.
+ *   primlist        [N*K, primlist_cap, 2] uint32: per primitive the (packet, list slot, step range) records;
+ *                   primlist_cap must be a multiple of 4 (lists are read 32 bytes at a time)
  * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
 int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                       const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,

@@ -34,6 +34,20 @@ def _render(ops, s, sl=slice(None), grad=False, gout=None):
     return rgba, None
 
 
+def _assert_euler(template, grad_template, gout, rgba):
+    """Euler homogeneity: rgb is linear in the slab rgb channels (alpha does not depend on them), so
+    sum T_rgb * dL/dT_rgb = sum dL/drgb * rgb.  With random-sign upstream gradients both sides are sums of cancelling terms
+    (C2, 8 cameras: 3.5e4 out of sum |terms| = 7.5e7), so the bound is stated against sum |terms|: 5e-7, fp32 level.  A
+    sample class missing from the backward shows at 1e-4 or more.  Measured (tools/debug_euler.py, gpurun_out/r03e): the
+    ray-centric backward (fp32 atomics) 2e-10; the primitive-centric one 1.1e-7 (round 2: 0.8e-7) -- v_cvt_rpi_i32_f32
+    rounds ties upward, a coherent +2^-25 relative per contribution."""
+    terms = template[..., :3].double() * grad_template[..., :3].double()
+    lhs, absum = terms.sum().item(), terms.abs().sum().item()
+    rhs = (gout[..., :3].double() * rgba[..., :3].double()).sum().item()
+    assert abs(lhs - rhs) <= 5e-7 * absum, (lhs, rhs, absum)
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
 ORACLE_CONFIGS = [
     # name, N, H, W, K, alpha_gain -- every BASELINE.json configuration is represented at its real image size and K;
     # the camera count is cut to what the float64 oracle finishes in seconds on the GPU box's host cores
@@ -80,8 +94,11 @@ def test_config_sizes_against_oracle(cfg, oracle64, oracle32):
     print(name, "diag", dg, "fragile", int(fr.sum()), "saturated rays", st["rays_saturated"], "of", st["rays_hit"])
     assert dg["list_overflow"] == 0 and dg["frontier_overflow"] <= 0.02 * max(1, dg["packets_hit"]), dg
     # no primitive may fall off the primitive-centric path at a BASELINE configuration (capacity heuristic check)
-    flags = int(handoff[N * K].item())   # read after the backward: bit 0 = some primitive left the primitive-centric path
-    assert flags == 0, flags
+    # read after the backward: bits 0-2 = some primitive left the primitive-centric path (list overflow, packed-key overflow,
+    # handed over by the backward); bit 3 = some primitive took the two-pass form of it (dynamic range of the upstream
+    # gradient: legitimate, rare on Gaussian gradients)
+    flags = int(handoff[N * K].item())
+    assert flags & 7 == 0, flags
     out = npf(rgba)
     scale = max(1.0, np.abs(ref).max())
     assert (np.abs(out - ref).max(-1)[~fr] > 2e-4 * scale).sum() == 0
@@ -178,9 +195,7 @@ def test_full_batch_properties(cfg):
         assert torch.isfinite(v).all()
     one, _ = _render(ops, s, slice(0, 1))
     assert torch.equal(one[0], rgba[0])
-    lhs = (s["template"][..., :3].double() * grads["template"][..., :3].double()).sum().item()
-    rhs = (gout[..., :3].double() * rgba[..., :3].double()).sum().item()
-    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    _assert_euler(s["template"], grads["template"], gout, rgba)
     _, grads2 = _render(ops, s, grad=True, gout=gout)
     assert torch.equal(grads["template"], grads2["template"])
     _hooks.force_ray_centric_backward = True
@@ -251,9 +266,7 @@ def test_c2_gradient_properties(c2_scene):
     for v in grads.values():
         assert torch.isfinite(v).all()
     # Euler homogeneity: rgb is linear in the slab rgb channels (alpha does not depend on them)
-    lhs = (s["template"][sl][..., :3].double() * grads["template"][..., :3].double()).sum().item()
-    rhs = (gout[..., :3].double() * rgba[..., :3].double()).sum().item()
-    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    _assert_euler(s["template"][sl], grads["template"], gout, rgba)
     # bit-reproducible slab gradient (integer LDS accumulation); pose gradients to fp32 round-off
     _, grads2 = _render(ops, s, sl, grad=True, gout=gout)
     assert torch.equal(grads["template"], grads2["template"])

@@ -73,8 +73,10 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
 @pytest.mark.parametrize("mode", BACKWARD_MODES)
 def test_heavy_tailed_upstream_gradient(ops, oracle64, mode):
     """0.1 % of the rays carry an upstream gradient 1e4 times the rest (a few bad pixels in an L1 image loss).  The
-    fixed-point scale of a primitive comes from the ray packets on ITS list, so primitives the outliers do not touch
-    keep full resolution: every primitive's slab gradient is held to 2e-4 of ITS OWN max |g| against float64."""
+    fixed-point scale of a round comes from the ray packets of THAT round's list entries, so primitives the outliers do
+    not touch keep full resolution; where an outlier's packet is on the list and the rays marched are far below it, the
+    primitive goes to the two-pass (residual) form of the kernel -- NOT to the ray-centric fallback: every primitive's
+    slab gradient is held to 2e-4 of ITS OWN max |g| against float64."""
     from ava256_amd.scene import make_scene
     N, H, W, K = 1, 96, 96, 512
     s = make_scene(N, H, W, K, device="cpu", seed=61, alpha_gain=2.0)
@@ -100,6 +102,11 @@ def test_heavy_tailed_upstream_gradient(ops, oracle64, mode):
     assert not (~live).any() or np.abs(got[~live]).max() == 0.0
     for k, refg in (("primpos", rgp), ("primrot", rgr), ("primscale", rgs)):
         assert cosine(grads[k], refg) >= 0.9999, k
+    if mode == "prim":  # the precision came from the two-pass kernel, no primitive was pushed to the fp32-atomic fallback
+        print("   two-pass primitives %d, handed over %d, flags %#x" % (diag["prims_two_pass"], diag["prims_handed_over"],
+                                                                        diag["handoff_flags"]))
+        assert diag["prims_two_pass"] > 0 and diag["handoff_flags"] & 8
+        assert diag["prims_handed_over"] == 0 and diag["handoff_flags"] & 7 == 0
 
 
 @pytest.mark.parametrize("mode", BACKWARD_MODES)

@@ -76,11 +76,17 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
         grads = {k: npf(t[k].grad) for k in names}
     torch.cuda.synchronize()
     d = mm.read_diag()
+    if mm.last_pl_count is not None:  # the hand-off words after the backward (include/mvp_abi.h): flags, and who owned what
+        NK = t["primpos"].shape[0] * t["primpos"].shape[1]
+        cnt = mm.last_pl_count[:NK].to(torch.int64) & 0xffffffff
+        d["handoff_flags"] = int(mm.last_pl_count[NK].item()) & 0xffffffff
+        d["prims_two_pass"] = int(((cnt >> 30) & 1).sum().item())        # marked for the two-pass (residual) kernel
+        d["prims_handed_over"] = int(((cnt >> 31) & 1).sum().item())     # handed to the ray-centric kernel by the backward
     mm.set_diag_buffer(None)
     mm.force_ray_centric_backward = False
     mm.primlist_cap_override = None
     mm.keep_raysat = False
-    mm.last_raysat = None
+    mm.last_raysat = mm.last_pl_count = None
     return npf(rgba), grads, d
 
 
