@@ -5,11 +5,39 @@ from . import _lib
 
 diag = None    # device int32[8] the march kernels accumulate MVP_DIAG_* counters into (include/mvp_abi.h)
 events = None  # list collecting (name, start_event, end_event) per C-ABI launch
-force_ray_centric_backward = False  # tests: skip the forward->backward hand-off so the fallback kernel runs
-primlist_cap_override = None        # tests: force a (small) per-primitive list capacity
 keep_raysat = False                 # tests: keep the last forward's raysat tensor in `last_raysat`
 last_raysat = None
 last_pl_count = None                # ... and its forward->backward hand-off counters ([N*K] counts, then flags, bounds)
+
+
+class patched_handoff:
+    """Tests / tools: run the forwards inside the `with` block with another hand-off allocation -- `cap=...`: that list
+    capacity per primitive (a small one pushes most primitives to the ray-centric kernel); `ray_centric=True`: no hand-off
+    buffers at all, so the ray-centric kernel owns everything.  Works by replacing mvpraymarch.alloc_handoff: the operator
+    itself reads no test switch."""
+
+    def __init__(self, cap=None, ray_centric=False):
+        self.cap, self.ray_centric = cap, ray_centric
+
+    def __enter__(self):
+        import importlib
+        m = importlib.import_module(__package__ + ".mvpraymarch")  # (the package re-exports a FUNCTION of that name)
+        self._m, self._orig = m, m.alloc_handoff
+        cap, ray_centric = self.cap, self.ray_centric
+
+        def alloc(N, H, W, K, dev):
+            if ray_centric:
+                return None, None, None, 0
+            rayaux, pl_count, _, _ = self._orig(N, H, W, K, dev)
+            return rayaux, pl_count, torch.empty((N * K, cap, 2), device=dev, dtype=torch.int32), cap
+
+        if cap is not None or ray_centric:
+            m.alloc_handoff = alloc
+        return self
+
+    def __exit__(self, *exc):
+        self._m.alloc_handoff = self._orig
+        return False
 
 
 def set_diag_buffer(t):

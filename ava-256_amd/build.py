@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libmvp_gfx950.so")
 SOURCES = ["raydirs.hip", "aabb.hip", "march.hip", "assemble.hip", "placement.hip", "gradclip.hip", "bgmlp.hip", "abi_misc.hip"]
 HEADERS = [os.path.join(CSRC, "mvp_device.h"), os.path.join(CSRC, "mvp_host.h"),
            os.path.join(ROOT, "include", "mvp_abi.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
 VARIANT_DIR = os.path.join(ROOT, "build_variants")
 
 
-def build_variant(name, defines, force=False):
+def build_variant(name, defines, force=False, extra_flags=()):
     """Compile a NON-product variant of the library into build_variants/libmvp_<name>.so (tests and timing
     experiments only, e.g. defines=["MVP_DEBUG_HOOKS"] for the build that honours the MVP_DEBUG_* environment)."""
     os.makedirs(VARIANT_DIR, exist_ok=True)
@@ -57,7 +57,7 @@ def build_variant(name, defines, force=False):
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    cmd = [_hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + ["-D" + d for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out + ".tmp"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:

@@ -118,6 +118,10 @@ constexpr uint32_t kFlagBwdPrecise = 8u;    // THIS backward left a primitive to
 constexpr uint32_t kCountDead = 0x80000000u;  // pl_count bit 31: "handed over by this backward" (cleared per call)
 constexpr uint32_t kCountPrecise = 0x40000000u;  // bit 30: "owned by the two-pass (residual) kernel in this backward"
 constexpr uint32_t kCountMask = 0x3fffffffu;     // the packets the forward counted
+// Per-packet word behind the tail of pl_count: bit 31 = the FORWARD could not append this packet to some primitive's list
+// (capacity), bit 30 = THIS backward wants the ray-centric kernel to march the packet (it is on the list of a primitive
+// that kernel owns; cleared per call), bits 29..0 = bits(max |grad_rayrgba| of the packet) >> 2, rounded up.
+constexpr uint32_t kPacketFwdOverflow = 0x80000000u, kPacketBwdWanted = 0x40000000u, kPacketMaxMask = 0x3fffffffu;
 constexpr uint32_t kNoSat = 0xffffffffu;
 #ifndef MVP_STRIP_ROWS
 #define MVP_STRIP_ROWS 3  // packet rows per dispatch strip (march_packet: packet -> (image, tile))
@@ -569,6 +573,12 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
 
     int n, tidx;
     if (!packet_of_block(p, b, n, tidx)) return;
+    if (BWD && !emit_all) {
+        // ray-centric backward for a FEW primitives: only the packets on their lists do anything -- marked by the forward
+        // (the packets it could not append) and by the primitive-centric kernel (the ones it could)
+        const uint32_t w_ = p.pl_count[(size_t)p.N * p.K + 3 + (size_t)n * p.tiles_x * p.tiles_y + tidx];
+        if ((w_ & (kPacketFwdOverflow | kPacketBwdWanted)) == 0u) return;
+    }
     const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
     const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
     const bool inimg = px < p.W && py < p.H;
@@ -940,20 +950,24 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             if (lane < nh) {
                 const size_t pk = (size_t)n * K + ent0;
                 const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
-                if (idx < (uint32_t)p.pl_cap)
+                if (idx < (uint32_t)p.pl_cap) {
                     p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)lane, (uint32_t)rg0);
-                else
+                } else {
                     raise_flag(flags, kFlagListOverflow);
+                    flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;  // (region zeroed by the host)
+                }
             }
         } else {
             for (int j = lane; j < nh; j += kWave) {
                 const int k = s_b[j] & 0xffffff;
                 const size_t pk = (size_t)n * K + k;
                 const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
-                if (idx < (uint32_t)p.pl_cap)
+                if (idx < (uint32_t)p.pl_cap) {
                     p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j]);
-                else
+                } else {
                     raise_flag(flags, kFlagListOverflow);
+                    flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;
+                }
             }
             if (!ranges_ok && lane == 0) raise_flag(flags, kFlagGlobal);
         }
@@ -1609,7 +1623,7 @@ __global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict
                      max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
         }
         mi = (uint32_t)wave_max((int)mi);  // all patterns are < 2^31: signed max is the same order
-        if (lane == 0) pmax[pk] = mi;
+        if (lane == 0) pmax[pk] = (pmax[pk] & kPacketFwdOverflow) | ((mi + 3u) >> 2);
     }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncounts; i += stride) {
@@ -1698,6 +1712,14 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
     const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
+    // ... and marches only the packets somebody asked it to: the ones the forward could not append are marked already,
+    // the recorded ones are marked here, by whoever hands a primitive over
+    auto want_ray_centric = [&]() {
+        uint32_t *pw = tail + 3 + (size_t)n * p.tiles_x * p.tiles_y;
+        const uint32_t m = min(cnt, (uint32_t)p.pl_cap);
+        for (uint32_t e = tid; e < m; e += kPrimBlock) atomicOr(pw + (list[e].x >> 9), kPacketBwdWanted);
+    };
+    if (dead && (flags & kFlagGlobal) == 0u && !RESID) want_ray_centric();  // (list overflow; the global flag marches all)
 
     // ---- stage the slab with its max |rgb| and max |opacity|; longest step range on the list ----
     float tmax = 0.f, amax = 0.f;
@@ -1760,6 +1782,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         if constexpr (WARP) fw = (float)(max(TD, max(TH, TW)) - 1) * (3.f * tmax * wrgb + amax * fa);
         if (!(fa < 1.0e30f) || !(fw < 1.0e30f)) {  // non-finite slab / raysat: the ray-centric kernel's case
             dead = true;
+            want_ray_centric();
             if (tid == 0) {
                 atomicOr(p.pl_count + pk, kCountDead);
                 raise_flag(tail, kFlagBwdHandoff);
@@ -1923,7 +1946,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                         shi = min(h0, ehi);
                     }
                 }
-                if (__ballot(slo <= shi) != 0ull) gq_hi = max(gq_hi, cload(pmax_n + tidx));
+                if (__ballot(slo <= shi) != 0ull) gq_hi = max(gq_hi, (cload(pmax_n + tidx) & kPacketMaxMask) << 2);
                 if (slo <= shi) {
                     // at most 127 steps per queued item (the len field and the buckets assume short crossings); a box
                     // that is deeper than that along some ray is handed to the ray-centric kernel (flagged below)
@@ -1964,6 +1987,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         // a ray crosses this box over more than 127 steps, a sample weight left its bound in an earlier round (signed
         // opacity), or the upstream gradient / the slab is not finite: not this kernel's case
         if (s_qn[2] != 0u || bad_bound) {
+            want_ray_centric();
             if (tid == 0) {
                 atomicOr(p.pl_count + pk, kCountDead);
                 raise_flag(tail, kFlagBwdHandoff);
@@ -2415,7 +2439,8 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     int tl = tid;
     asm volatile("; late address base" : "+s"(pkl), "+v"(tl));
     float4 *gT4l = reinterpret_cast<float4 *>(p.grad_tplate) + pkl * (size_t)V;
-    if (s_qn[2] != 0u) {  // a weight left [-1, 1] in the last round: the ray-centric kernel (fp32 atomics) owns it
+    if (s_qn[2] != 0u) {  // a weight left its bound in the last round: the ray-centric kernel (fp32 atomics) owns it
+        want_ray_centric();
         if (tl == 0) {
             atomicOr(p.pl_count + pkl, kCountDead);
             raise_flag(p.pl_count + (size_t)p.N * K, kFlagBwdHandoff);
@@ -2634,7 +2659,8 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
         if ((long long)p.tiles_x * p.tiles_y > (1ll << 23)) {  // packet index does not fit the packed list entry
             p.pl_count = nullptr, p.pl_list = nullptr;        // backward will see the global flag set below
         }
-        hipError_t e = hipMemsetAsync(primlist_count, 0, sizeof(uint32_t) * ((size_t)N * K + 3), st);
+        hipError_t e = hipMemsetAsync(primlist_count, 0,
+                                      sizeof(uint32_t) * ((size_t)N * K + 3 + (size_t)N * p.tiles_x * p.tiles_y), st);
         if (e != hipSuccess) return (int)e;
         if (!p.pl_count) {
             e = hipMemsetD32Async((hipDeviceptr_t)(primlist_count + (size_t)N * K), (int)kFlagGlobal, 1, st);

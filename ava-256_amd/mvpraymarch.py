@@ -16,17 +16,67 @@ from torch.autograd import Function
 from . import _hooks, _lib
 from ._tensors import aligned, ptr, require_device_f32, stream_ptr
 
-def primlist_capacity(H, W, K):
-    """Per-primitive capacity of the packet lists handed from forward to backward.  On head-like scenes a packet
-    (8x8 pixels) lists ~19 primitives and ~46 % of the packets hit anything (measured, C2), so a primitive is listed by
-    ~9-10 * packets / K packets; four times that, at least 32.  Primitives that exceed it are handled by the
-    ray-centric kernel (correct, slower)."""
-    if _hooks.primlist_cap_override is not None:
-        return int(_hooks.primlist_cap_override)
+class _ListDemand:
+    """What the forward's per-primitive counters said the lists of one problem shape need (they keep counting past the
+    capacity): the high-water mark, and one measurement in flight (device max -> pinned word -> event)."""
+    __slots__ = ("hwm", "word", "event")
+
+    def __init__(self):
+        self.hwm, self.word, self.event = 0, None, None
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            self.hwm = max(self.hwm, int(self.word[0]))
+            self.event = None
+
+
+_LIST_DEMAND = {}  # (device index, H, W, K) -> _ListDemand
+
+
+def primlist_capacity(H, W, K, device=None):
+    """Per-primitive capacity of the packet lists handed from forward to backward.  First call of a shape: a heuristic
+    -- on head-like scenes a packet (8x8 pixels) lists ~19 primitives and ~46 % of the packets hit anything (measured, C2),
+    so a primitive is listed by ~9-10 * packets / K packets; four times that, at least 32.  Afterwards: 1.25 x the largest
+    demand any primitive of this shape has shown so far (`note_list_demand`, read one call late and without a host
+    synchronisation), so a close-up camera costs ONE iteration with some primitives on the ray-centric kernel, not all
+    of them.  Multiple of 8 (the library reads lists 32 bytes at a time), at most 2048."""
     packets = ((H + 7) // 8) * ((W + 7) // 8)
-    avg = 10.0 * packets / max(K, 1)
-    cap = int(min(max(32, 4 * avg), 2048))
-    return (cap + 7) // 8 * 8
+    cap = max(32.0, 4 * 10.0 * packets / max(K, 1))
+    st = _LIST_DEMAND.get((getattr(device, "index", None), H, W, K)) if device is not None else None
+    if st is not None:
+        st.poll()
+        if st.hwm > 0:
+            cap = max(32.0, 1.25 * st.hwm)
+    return (int(min(cap, 2048)) + 7) // 8 * 8
+
+
+def note_list_demand(pl_count, N, H, W, K):
+    """Queue a read-back of max over primitives of the packets the forward counted (stream-ordered behind it, before any
+    backward marks the counters): a device reduction, a 4-byte copy into pinned memory and an event.  At most one in
+    flight per shape; nothing happens while a stream is being captured."""
+    dev = pl_count.device
+    if N * K == 0 or torch.cuda.is_current_stream_capturing():
+        return
+    st = _LIST_DEMAND.setdefault((dev.index, H, W, K), _ListDemand())
+    st.poll()
+    if st.event is not None:
+        return
+    if st.word is None:
+        st.word = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+    st.word.copy_(pl_count[:N * K].max().reshape(1), non_blocking=True)
+    st.event = torch.cuda.Event()
+    st.event.record(torch.cuda.current_stream(dev))
+
+
+def alloc_handoff(N, H, W, K, dev):
+    """Hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record, per-primitive
+    counters + flags + per-packet words (zeroed by the library), and per primitive the list of ray packets that touch it.
+    Returns (rayaux, pl_count, pl_list, pl_cap)."""
+    pl_cap = primlist_capacity(H, W, K, dev)
+    rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
+    pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
+    pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
+    return rayaux, pl_count, pl_list, pl_cap
 
 
 def build_accel(primtransfin, algo, fixedorder=False):
@@ -116,14 +166,7 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
     pl_cap = 0
     if gradmode:
         raysat = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
-        if not _hooks.force_ray_centric_backward:
-            # hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record
-            # and, per primitive, the list of ray packets that touch it
-            pl_cap = primlist_capacity(H, W, K)
-            rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
-            # counters + flags (zeroed by the library) + per-packet scratch of the backward (include/mvp_abi.h)
-            pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
-            pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
+        rayaux, pl_count, pl_list, pl_cap = alloc_handoff(N, H, W, K, dev)
     with torch.cuda.device(dev), _hooks.timed("march_forward", dev):
         if cams is None:
             _lib.check(_lib.get_lib().mvp_march_forward(
@@ -138,6 +181,9 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
                 ptr(rayrgba), ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp,
                 ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_forward_cams")
 
+    if pl_count is not None:
+        with torch.cuda.device(dev):
+            note_list_demand(pl_count, N, H, W, K)
     if _hooks.keep_raysat:
         _hooks.last_raysat = raysat
         _hooks.last_pl_count = pl_count

@@ -21,13 +21,15 @@ The forward keeps the hand-off buffers of the primitive-centric backward (rayaux
 of the `rayrgba` tensor the reference's autograd Function saves and passes back (the saved tensor is unpacked as a new
 tensor object over the same storage), so the backward runs the fast path; the entry dies with that storage.
 """
+import importlib
 import weakref
 
 import torch
 
 from . import _hooks, _lib
 from ._tensors import aligned, ptr, require_device_f32, stream_ptr
-from .mvpraymarch import primlist_capacity
+
+_op = importlib.import_module(__package__ + ".mvpraymarch")  # (the package re-exports a function of that name)
 
 # rayrgba.data_ptr() -> ((N, H, W, K), rayaux, pl_count, pl_list, pl_cap).  An entry lives exactly as long as the
 # rayrgba STORAGE: a finaliser on the storage object removes it (a forward whose backward never runs leaks nothing, and
@@ -116,10 +118,7 @@ def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildre
     pl_cap = 0
     if raysat is not None:
         require_device_f32("raysat", raysat)
-        pl_cap = primlist_capacity(H, W, K)
-        rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
-        pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
-        pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
+        rayaux, pl_count, pl_list, pl_cap = _op.alloc_handoff(N, H, W, K, dev)
         _handoff_put(rayrgba, (N, H, W, K), (rayaux, pl_count, pl_list, pl_cap))
     with torch.cuda.device(dev):
         _lib.check(_lib.get_lib().mvp_march_forward(
@@ -127,6 +126,8 @@ def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildre
             ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template), WD, WH, WW, ptr(warp), ptr(rayrgba), ptr(raysat),
             ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, float(fadescale), float(fadeexp), ptr(_hooks.diag),
             stream_ptr(dev)), "mvp_march_forward")
+        if pl_count is not None:
+            _op.note_list_demand(pl_count, N, H, W, K)
 
 
 def raymarch_backward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildren, nodeaabb, primpos, grad_primpos,

@@ -198,11 +198,8 @@ def test_full_batch_properties(cfg):
     _assert_euler(s["template"], grads["template"], gout, rgba)
     _, grads2 = _render(ops, s, grad=True, gout=gout)
     assert torch.equal(grads["template"], grads2["template"])
-    _hooks.force_ray_centric_backward = True
-    try:
+    with _hooks.patched_handoff(ray_centric=True):
         _, gr = _render(ops, s, slice(0, 1), grad=True, gout=gout[:1])
-    finally:
-        _hooks.force_ray_centric_backward = False
     gt = grads["template"][:1]
     assert (gr["template"] - gt).abs().max().item() <= 1e-3 * gt.abs().max().item()
     for k in ("primpos", "primrot", "primscale"):
@@ -271,11 +268,8 @@ def test_c2_gradient_properties(c2_scene):
     _, grads2 = _render(ops, s, sl, grad=True, gout=gout)
     assert torch.equal(grads["template"], grads2["template"])
     # the two backward implementations agree
-    _hooks.force_ray_centric_backward = True
-    try:
+    with _hooks.patched_handoff(ray_centric=True):
         _, gr = _render(ops, s, slice(0, 2), grad=True, gout=gout[:2])
-    finally:
-        _hooks.force_ray_centric_backward = False
     gt = grads["template"][:2]
     assert (gr["template"] - gt).abs().max().item() <= 1e-3 * gt.abs().max().item()
     for k in ("primpos", "primrot", "primscale"):

@@ -309,3 +309,39 @@ def test_fused_camera_entry_point_is_bit_identical(ops, pixel_form):
     with pytest.raises(TypeError):
         ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], pc, s["volradius"], s["stepsize"],
                                      (s["primpos"], s["primrot"], s["primscale"]), s["template"], not_an_option=1)
+
+
+def test_list_capacity_follows_the_demand(ops, oracle64):
+    """A close-up camera (focal x 4): primitives cover many more ray packets than the first-call heuristic of the list
+    capacity allows.  First call: the overflowed primitives go through the ray-centric kernel -- which marches ONLY the
+    packets on their lists (per-packet marks), not the whole image; the forward's counters say what would have been
+    needed, the operator reads them back without a host synchronisation, and the second call sizes the lists from that:
+    no overflow, everything primitive-centric.  Both calls match the float64 oracle."""
+    from ava256_amd import _hooks
+    import importlib
+    op = importlib.import_module("ava256_amd.mvpraymarch")
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 256, 256, 2048          # C3-like density of primitives per packet, kept small for the oracle
+    s = make_scene(N, H, W, K, device="cpu", seed=23, alpha_gain=4.0)
+    s["focal"] = s["focal"] * 4.0
+    op._LIST_DEMAND.pop((0, H, W, K), None)
+    cap0 = op.primlist_capacity(H, W, K, torch.device("cuda", 0))
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
+    ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    gout = np.random.default_rng(4).normal(size=ref_rgba.shape)
+    fragile = FragileRays(ref_sat, st["margin"], gout)
+    ref = dict(zip(("primpos", "primrot", "primscale", "template"), oracle64.march_backward(*a, ref_sat, gout)))
+    seen = []
+    for call in range(2):
+        rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode="prim")
+        assert np.abs(rgba - ref_rgba).max() <= FWD_TOL * max(1.0, np.abs(ref_rgba).max())
+        ref_m = dict(zip(("primpos", "primrot", "primscale", "template"), oracle64.march_backward(*a, ref_sat, fragile.masked())))
+        _check_grads(grads, ref_m, "call %d" % call)
+        torch.cuda.synchronize()
+        seen.append((diag["handoff_flags"], op.primlist_capacity(H, W, K, torch.device("cuda", 0))))
+    (flags1, cap1), (flags2, cap2) = seen
+    print("list capacity: heuristic %d -> measured demand -> %d; flags %#x then %#x" % (cap0, cap1, flags1, flags2))
+    assert flags1 & 1, "the scene is meant to overflow the heuristic capacity on the first call"
+    assert cap1 > cap0 and cap2 == cap1
+    assert flags2 & 7 == 0, flags2          # second call: nothing left the primitive-centric path

@@ -53,8 +53,7 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
     from ava256_amd import _hooks as mm
     diag = torch.zeros(8, dtype=torch.int32, device="cuda")
     mm.set_diag_buffer(diag)
-    mm.force_ray_centric_backward = (mode == "ray")
-    mm.primlist_cap_override = 4 if mode == "cap4" else None
+    handoff = mm.patched_handoff(cap=4 if mode == "cap4" else None, ray_centric=(mode == "ray"))
     mm.keep_raysat = True
     t = dict(raypos=to_dev(raypos), raydir=to_dev(raydir), tminmax=to_dev(tminmax), primpos=to_dev(primpos),
              primrot=to_dev(primrot), primscale=to_dev(primscale), template=to_dev(template))
@@ -64,7 +63,7 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
         names = names + ("warp",)
     for k in names:
         t[k].requires_grad_(grad_out is not None)
-    with torch.set_grad_enabled(grad_out is not None):
+    with torch.set_grad_enabled(grad_out is not None), handoff:
         rgba = ops.mvpraymarch(t["raypos"], t["raydir"], float(stepsize), t["tminmax"],
                                (t["primpos"], t["primrot"], t["primscale"]), t["template"], t.get("warp"),
                                algo=1 if warp is not None else 0, fadescale=float(fadescale), fadeexp=float(fadeexp))
@@ -83,8 +82,6 @@ def _march(ops, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, 
         d["prims_two_pass"] = int(((cnt >> 30) & 1).sum().item())        # marked for the two-pass (residual) kernel
         d["prims_handed_over"] = int(((cnt >> 31) & 1).sum().item())     # handed to the ray-centric kernel by the backward
     mm.set_diag_buffer(None)
-    mm.force_ray_centric_backward = False
-    mm.primlist_cap_override = None
     mm.keep_raysat = False
     mm.last_raysat = mm.last_pl_count = None
     return npf(rgba), grads, d

@@ -17,7 +17,7 @@ warp = (torch.stack([xx, yy, zz], -1)[None, None] + 0.05 * torch.randn(N, K, 8, 
 rp, rd, tm = ops.compute_raydirs(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"], s["volradius"])
 out = {}
 for mode in ("prim", "ray"):
-    _hooks.force_ray_centric_backward = mode == "ray"
+    handoff = _hooks.patched_handoff(ray_centric=(mode == "ray"))
     t = {k: s[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
     w = warp.clone().requires_grad_(True)
     gout = torch.randn(N, H, W, 4, device="cuda", generator=g)
@@ -27,7 +27,8 @@ for mode in ("prim", "ray"):
         for v in list(t.values()) + [w]:
             v.grad = None
         ev[0].record()
-        rgba = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], w, algo=1)
+        with handoff:
+            rgba = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], w, algo=1)
         ev[1].record()
         rgba.backward(gout)
         ev[2].record()
@@ -36,5 +37,4 @@ for mode in ("prim", "ray"):
             fw += ev[0].elapsed_time(ev[1]) / 3
             bw += ev[1].elapsed_time(ev[2]) / 3
     out[mode] = dict(fwd_ms=round(fw, 3), bwd_ms=round(bw, 3), gw_norm=float(w.grad.norm()), gt_norm=float(t["template"].grad.norm()))
-_hooks.force_ray_centric_backward = False
 print(json.dumps(dict(N=N, H=H, W=W, K=K, **out)))

@@ -43,9 +43,8 @@ if __name__ == "__main__":
         else:
             print("   grad_template vs product: max-abs %.3e of max |g| %.3e" % ((g - ref).abs().max().item(), ref.abs().max().item()))
     _lib.use_library(None)
-    _hooks.force_ray_centric_backward = True
-    lhs, rhs, absum, g = residual(s, gout[:2], slice(0, 2))
+    with _hooks.patched_handoff(ray_centric=True):
+        lhs, rhs, absum, g = residual(s, gout[:2], slice(0, 2))
     print("%-40s lhs %.4f rhs %.4f diff %+.4f  (2 cameras)" % ("ray-centric (fp32 atomics)", lhs, rhs, lhs - rhs))
-    _hooks.force_ray_centric_backward = False
     lhs2, rhs2, absum2, g2 = residual(s, gout[:2], slice(0, 2))
     print("%-40s lhs %.4f rhs %.4f diff %+.4f  (2 cameras)" % ("product, same 2 cameras", lhs2, rhs2, lhs2 - rhs2))
