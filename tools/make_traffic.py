@@ -6,7 +6,6 @@ right after the gpurun call returned, before the kernels change again).  bench.p
 
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
 (MI355X_MICROARCH.md, "HBM"); both counters are in units of 1024 B."""
-import csv
 import json
 import os
 import subprocess
@@ -17,13 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def per_dispatch(path, counter):
     out = {}
-    for r in csv.DictReader(open(path)):
-        if r["counter"] != counter:
+    for line in list(open(path))[1:]:  # kernel,dispatches,counter,sum,per_dispatch -- kernel names contain commas
+        k, _, ctr, _, per = line.rstrip("\n").rsplit(",", 4)
+        if ctr != counter:
             continue
-        k = r["kernel"]
         name = "march_forward" if "march_kernel<false" in k else "march_backward" if "bwd_prim_kernel" in k else None
         if name:
-            out[name] = out.get(name, 0.0) + float(r["per_dispatch"])
+            out[name] = out.get(name, 0.0) + float(per)
     return out
 
 
