@@ -135,10 +135,15 @@ def save_raydirs(name, N=2, H=12, W=20, volradius=1.0):
     lines = src.splitlines()
     first = next(i for i, ln in enumerate(lines) if "run pytorch version" in ln) + 1
     last = next(i for i, ln in enumerate(lines) if i > first and ln.strip() == "sample0 = raydir")
+    import hashlib
     import textwrap
     stmt = textwrap.dedent("\n".join(lines[first:last]))
+    # the slice is located by two strings of the upstream file: executed only if it is still the reviewed statement
+    # (utils.py:123-149), and with nothing but torch and the inputs in reach
+    assert hashlib.sha256(stmt.encode()).hexdigest() == \
+        "ba484e84f53f7f2de9a63f2f3c976b281eddaff66b22b48c8bb9ec0d9b353a6f", "extensions/utils/utils.py changed: re-read it"
     env = dict(torch=torch, H=H, W=W, _viewpos=viewpos, _viewrot=viewrot, _focal=focal, _princpt=princpt,
-               _pixelcoords=pixelcoords)
+               _pixelcoords=pixelcoords, __builtins__={})
     exec(compile(stmt, "refutils_dense_rays", "exec"), env)
     raypos, raydir, tminmax = env["raypos"], env["raydir"], env["tminmax"]
     torch.set_default_dtype(torch.float32)
