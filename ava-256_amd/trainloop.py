@@ -138,7 +138,7 @@ class SlabDecoderStandIn(nn.Module):
         cs = torch.maximum((pm[:, n1] - pm).norm(dim=-1), (pm[:, n2] - pm).norm(dim=-1)).amax(dim=0)  # [K]
         if store:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.is_available() and dist.is_initialized():
                 dist.all_reduce(cs, op=dist.ReduceOp.MAX)
         warps_vec = 2.0 / cs
         fresh = (self.adaptwarps.max() == 0)

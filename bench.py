@@ -106,11 +106,20 @@ def env_ranks():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend, rank, world, dev):
-    """One process per GPU (backend "nccl" = RCCL) or per CPU rank (backend "gloo", tests).  None when world == 1."""
-    if world == 1:
+def init_process_group(backend, rank, world, dev, force=False):
+    """One process per GPU (backend "nccl" = RCCL) or per CPU rank (backend "gloo", tests).  None when world == 1 --
+    unless `force` (--dist-smoke): then a one-rank group is made, so that every collective of the N > 1 path (barrier,
+    MAX-reduce, DDP's bucket all-reduce, the adaptwarps MAX) runs through RCCL on a single GPU."""
+    if world == 1 and not force:
         return None
     import torch.distributed as dist
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
@@ -200,7 +209,7 @@ def kernel_averages(events):
     return {k: sum(v) / len(v) for k, v in kt.items()}
 
 
-def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg):
+def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None):
     """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object."""
     from ava256_amd import _hooks as mm
     from ava256_amd.trainloop import (BackgroundMLPStandIn, CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel,
@@ -213,7 +222,8 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
                                bgmodel=BackgroundMLPStandIn(ncams, nident) if with_bg else None,
                                encoder=CodeEncoderStandIn()).to(dev)
     nparams = sum(p.numel() for p in model.parameters())
-    tr = Trainer(model, ddp=world > 1, device_ids=[local_rank] if world > 1 else None)
+    ddp = (world > 1) if ddp is None else ddp
+    tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None)
     state = {}
 
     def step():
@@ -228,7 +238,7 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
     px = N * H * W
     out = {"workload": "%s: %d frames/GPU, %dx%d, K=%d" % (workload, N, H, W, K), "iters_per_s": steps / elapsed,
            "ms_per_iter": 1e3 * elapsed / steps, "steps": steps, "frames_per_s": N * world * steps / elapsed,
-           "allreduce_mb": nparams * 4e-6 if world > 1 else 0.0, "param_mb": nparams * 4e-6,
+           "allreduce_mb": nparams * 4e-6 if ddp else 0.0, "param_mb": nparams * 4e-6,
            "kernel_ms": kernel_averages(events), "final_loss": float(state["loss"]),
            "background_mlp": ("fused MFMA kernels (csrc/bgmlp.hip: bf16 operands, fp32 accumulation), %.1f GFLOP fwd per "
                               "iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
@@ -274,6 +284,10 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     ap.add_argument("--no-train", action="store_true", help="skip the train leg (profiling runs of the march kernels)")
     ap.add_argument("--no-render", action="store_true", help="skip the no-grad render timing (profiling runs: keeps the "
                                                              "per-kernel averages those of the training-path launches)")
+    ap.add_argument("--dist-smoke", action="store_true",
+                    help="with ONE rank: still create the process group and wrap the train model in DDP, so that the "
+                         "collectives of the N > 1 path run through RCCL on a single GPU (a test of the plumbing, not a "
+                         "measurement)")
     ap.add_argument("--mode", default="march", choices=["march", "train"],
                     help="march (default, the contract metric + a `train` object); train: only the training loop, as "
                          "the headline value (iterations/s)")
@@ -292,11 +306,11 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         dev = torch.device("cuda", local_rank)
     else:
         dev = torch.device(device)  # tests only
-    dist = init_process_group(backend, rank, world, dev)
+    dist = init_process_group(backend, rank, world, dev, force=args.dist_smoke)
 
     if args.mode == "train":
         t = train_leg(args.workload, args.steps, args.warmup, rank, local_rank, world, dev, dist,
-                      with_bg=args.workload != "C2")
+                      with_bg=args.workload != "C2", ddp=(world > 1 or args.dist_smoke))
         if rank == 0:
             print(json.dumps({
                 "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",

@@ -107,3 +107,32 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path, monkeypatch, ca
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak"
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 2 * 3 * 16 * 16) <= 1e-6 * 2 * 3 * 16 * 16
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["march", "train"])
+def test_collectives_of_the_multi_gpu_path_run_through_rccl_on_one_gpu(mode):
+    """No multi-GPU node is available to these tests, and RCCL refuses two ranks on one device -- but a ONE-rank group
+    still takes every collective of the N > 1 path through RCCL: `bench.py --dist-smoke` initialises the "nccl" group with
+    `device_id`, runs the barriers and the MAX all-reduce of the elapsed time around the timed steps, and (train mode)
+    wraps the model in DistributedDataParallel with the one flat gradient bucket and runs the decoder's adaptwarps MAX
+    all-reduce.  The line must come out, with finite numbers."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dist-smoke", "--steps", "3", "--warmup", "1", "--workload", "C1",
+           "--no-cpu-baseline", "--no-train", "--no-render"]
+    if mode == "train":
+        cmd += ["--mode", "train"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["ms_per_step"] > 0
+    if mode == "train":
+        t = j["train"]
+        assert t["allreduce_mb"] > 0 and t["final_loss"] == t["final_loss"]      # DDP was on; the loss is finite
