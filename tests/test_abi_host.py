@@ -143,3 +143,25 @@ def test_no_cpu_fallback():
     for fn in os.listdir(pkg):
         if fn.endswith(".py"):
             assert "oracle" not in open(os.path.join(pkg, fn)).read().replace("no oracle", ""), fn
+
+
+def test_list_capacity_policy_on_the_host():
+    """Host logic of the forward->backward list capacity (ava-256_amd/mvpraymarch.py): the first call of a shape uses the
+    heuristic, later calls 1.25 x the high-water mark of the measured demand, always a multiple of 8 (the library reads
+    lists 32 bytes at a time and rejects capacities that are not a multiple of 4), at least 32, at most 2048."""
+    import importlib
+    op = importlib.import_module("ava256_amd.mvpraymarch")
+    dev = torch.device("cuda", 0)   # only its index is used as a key
+    key = (0, 512, 512, 4096)
+    op._LIST_DEMAND.pop(key, None)
+    cap0 = op.primlist_capacity(512, 512, 4096, dev)
+    assert cap0 == 40 and cap0 % 8 == 0                        # 4 x 10 x 4096 packets / 4096 primitives
+    assert op.primlist_capacity(64, 64, 16384, dev) == 32      # never below 32
+    assert op.primlist_capacity(4096, 4096, 16, dev) == 2048   # never above 2048
+    st = op._LIST_DEMAND.setdefault(key, op._ListDemand())
+    for hwm, want in ((10, 32), (61, 80), (100, 128), (5000, 2048)):
+        st.hwm = hwm
+        cap = op.primlist_capacity(512, 512, 4096, dev)
+        assert cap == want and cap % 8 == 0 and cap >= min(hwm, 2048), (hwm, cap)
+    op._LIST_DEMAND.pop(key, None)
+    assert op.primlist_capacity(512, 512, 4096, None) == cap0  # no device: the heuristic
