@@ -2,7 +2,8 @@
 # tools/evidence.sh <tag> -- the per-round evidence run on the GPU box (via gpurun): rocprofv3 kernel stats of the default
 # bench line, separate FETCH_SIZE / WRITE_SIZE / SQ / TA / LDS counter passes of the march kernels, and kernel stats + MFMA
 # counters of the train leg (C3: 4 frames, fused bf16 background MLP), the MLP and warp-field microbenchmarks.  Everything lands in gpurun_out/<tag>*/ ; copy what is to
-# be judged into profiles/.
+# be judged into profiles/ and run `python tools/make_traffic.py profiles/<tag>_pmc_fetch.csv profiles/<tag>_pmc_write.csv` in the
+# build container (it stamps traffic.json with the commit).
 set -u
 TAG=$1
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p $O
@@ -14,6 +15,7 @@ bash tools/pmc.sh ${TAG}_write "WRITE_SIZE" $M > $O/write.log 2>&1
 bash tools/pmc.sh ${TAG}_sq "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" $M > $O/sq.log 2>&1
 bash tools/pmc.sh ${TAG}_ta "TA_TA_BUSY_sum TA_BUSY_max TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" $M > $O/ta.log 2>&1
 bash tools/pmc.sh ${TAG}_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $M > $O/lds.log 2>&1
+bash tools/pmc.sh ${TAG}_tcc "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" $M > $O/tcc.log 2>&1
 bash tools/pmc_all.sh ${TAG}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA" --mode train --workload C3 --steps 4 --warmup 2 > $O/mfma.log 2>&1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/prof_train; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o train -- python bench.py --mode train --workload C3 --steps 6 --warmup 2 > $O/train_prof.log 2>&1
