@@ -266,13 +266,24 @@ static void tri_fetch(const real *G, int C, const tri_t *tr, real *out) {
  * mvpo_set_ray_diagnostics and valid for the next calls until reset):
  *   margin[r]   = min over the evaluated samples of |alpha_after_sample - 1|  (INFINITY when the ray takes no sample):
  *                 how close the saturation decision `newalpha >= 1` (primaccum.h:71) came to flipping;
- *   hitcount[r] = primitives listed for the ray (utils.h:757-781);   nsamples[r] = samples evaluated. */
-static real *g_margin = NULL;
+ *   hitcount[r] = primitives listed for the ray (utils.h:757-781);   nsamples[r] = samples evaluated;
+ *   edge[r]     = the largest opacity increment |alpha * stepsize| among the (step, primitive) pairs whose INCLUSION came
+ *                 within eps of flipping: the strict box test (primtransf.h:112-117) with max|y_i| within eps * max|scale_i|
+ *                 of 1 (eps in world units: what fp32 position round-off can move a sample), or the march bound
+ *                 `t < tmax + 1e-5` (subset_kernel.h:76) within eps.  0 when no decision was close.  Like saturation these
+ *                 are discontinuities of the rendering in the sample position: an fp32 march may decide them differently
+ *                 from this float64 one, and then differs by that increment. */
+static real *g_margin = NULL, *g_edge = NULL;
+static real g_edge_eps = 0;
 static int *g_hitcount = NULL, *g_nsamples = NULL;
 void mvpo_set_ray_diagnostics(real *margin, int *hitcount, int *nsamples) {
     g_margin = margin;
     g_hitcount = hitcount;
     g_nsamples = nsamples;
+}
+void mvpo_set_edge_diagnostics(real *edge, real eps) {
+    g_edge = edge;
+    g_edge_eps = eps;
 }
 
 /* warp may be NULL (algo 0).  With a warp field [N,K,WD,WH,WW,3] the template is sampled at y1 = warp(y0)
@@ -305,7 +316,7 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
             st3 += ovf;
             real rgba[4] = {0, 0, 0, 0}, sat3[3] = {-1, -1, -1};
             int sat = 0, myns = 0;
-            real margin = INFINITY;
+            real margin = INFINITY, edge = 0;
             rtmin = rmax(rtmin, tmn); /* subset_kernel.h:63-64 */
             rtmax = rmin(rtmax, tmx);
             if (nh > 0 && rtmin < INFINITY) {
@@ -322,6 +333,28 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
                         int k = hits[ks];
                         srt_t s;
                         srt_forward(pp + (size_t)k * 3, pr + (size_t)k * 9, ps + (size_t)k * 3, x, &s);
+                        if (g_edge && !sat) { /* diagnostics only: was the inclusion of this pair a close call? */
+                            const real *sc = ps + (size_t)k * 3;
+                            real cheb = rmax(R_ABS(s.y[0]), rmax(R_ABS(s.y[1]), R_ABS(s.y[2])));
+                            real smax = rmax(R_ABS(sc[0]), rmax(R_ABS(sc[1]), R_ABS(sc[2])));
+                            int near_box = R_ABS(cheb - (real)1) < g_edge_eps * smax;
+                            int near_t = R_ABS(t - (rtmax + (real)1e-5)) < g_edge_eps && cheb < (real)1 + g_edge_eps * smax;
+                            if (near_box || near_t) {
+                                real yc[3];
+                                for (int j = 0; j < 3; ++j) yc[j] = rmin(rmax(s.y[j], (real)-0.999999), (real)0.999999);
+                                real y1c[3] = {yc[0], yc[1], yc[2]};
+                                if (warp) {
+                                    tri_t tw;
+                                    tri_setup(WD, WH, WW, yc, &tw);
+                                    tri_fetch(warp + ((size_t)n * K + k) * VW * 3, 3, &tw, y1c);
+                                }
+                                tri_t trc;
+                                tri_setup(TD, TH, TW, y1c, &trc);
+                                real vc[4];
+                                tri_fetch(T + (size_t)k * V * 4, 4, &trc, vc);
+                                edge = rmax(edge, R_ABS(vc[3] * fade_of(yc, fadescale, fadeexp) * stepsize));
+                            }
+                        }
                         if (srt_valid(s.y) && !sat && t < rtmax + (real)1e-5) {
                             st2 += 1;
                             real fade = fade_of(s.y, fadescale, fadeexp);
@@ -362,6 +395,7 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
             }
             st5 += sat;
             if (g_margin) g_margin[r] = margin;
+            if (g_edge) g_edge[r] = edge;
             if (g_hitcount) g_hitcount[r] = nh;
             if (g_nsamples) g_nsamples[r] = myns;
             for (int j = 0; j < 4; ++j) rayrgba[r * 4 + j] = rgba[j];

@@ -71,7 +71,8 @@ class Oracle:
         return out
 
     def march_forward(self, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template,
-                      fadescale=8.0, fadeexp=8.0, maxhitboxes=512, want_raysat=True, nodeaabb=None, warp=None, ray_diagnostics=False):
+                      fadescale=8.0, fadeexp=8.0, maxhitboxes=512, want_raysat=True, nodeaabb=None, warp=None, ray_diagnostics=False,
+                      edge_eps=4e-6):
         raypos, raydir, tminmax, primpos, primrot, primscale, template = map(
             self._a, (raypos, raydir, tminmax, primpos, primrot, primscale, template))
         N, H, W = raypos.shape[:3]
@@ -95,6 +96,8 @@ class Oracle:
             hitcount = np.empty((N, H, W), np.int32)
             nsamples = np.empty((N, H, W), np.int32)
             self.lib.mvpo_set_ray_diagnostics(self._p(margin), self._p(hitcount), self._p(nsamples))
+            edge = np.empty((N, H, W), self.dtype)
+            self.lib.mvpo_set_edge_diagnostics(self._p(edge), self._creal(edge_eps))
         rc = self.lib.mvpo_march_forward(
             N, H, W, K, self._p(raypos), self._p(raydir), self._creal(stepsize), self._p(tminmax),
             self._p(nodeaabb), self._p(primpos), self._p(primrot), self._p(primscale), TD, TH, TW,
@@ -102,11 +105,14 @@ class Oracle:
             self._creal(fadeexp), int(maxhitboxes), stats.ctypes.data_as(ctypes.c_void_p))
         if ray_diagnostics:
             self.lib.mvpo_set_ray_diagnostics(None, None, None)
+            self.lib.mvpo_set_edge_diagnostics(None, self._creal(0.0))
         assert rc == 0
         names = ["rays_hit", "list_len_sum", "samples", "list_overflow", "steps", "rays_saturated"]
         st = dict(zip(names, stats[:6].tolist()))
         if ray_diagnostics:  # per-ray: saturation margin min|alpha_after - 1|, listed primitives, evaluated samples
-            st.update(margin=margin, hitcount=hitcount, nsamples=nsamples)
+            # edge: largest opacity increment among the inclusion decisions (box face, march bound) that came within
+            # edge_eps world units of flipping (mvp_oracle.c, mvpo_set_edge_diagnostics)
+            st.update(margin=margin, hitcount=hitcount, nsamples=nsamples, edge=edge)
         return rgba, raysat, st
 
     def march_backward(self, raypos, raydir, stepsize, tminmax, primpos, primrot, primscale, template, raysat,

@@ -36,6 +36,7 @@ def load_krt_400940():
 
 
 SAT_BAND = 1e-4  # a ray may disagree with the float64 oracle on its saturating sample only inside this band
+EDGE_JUMP = 5e-5  # ... and on including a sample that sits on a box face / the march bound (oracle `edge`, see FragileRays)
 
 
 class FragileRays:
@@ -43,20 +44,30 @@ class FragileRays:
     passes 1.0 by less than fp32 round-off may saturate at a different sample than in float64.  Such rays get zero
     upstream gradient on both sides -- but ONLY when the ORACLE says they are borderline: `margin` is the float64
     oracle's own min over the ray's samples of |alpha_after_sample - 1| (Oracle.march_forward(ray_diagnostics=True)).
-    A ray whose kernel `raysat` disagrees with the oracle's although its margin is >= SAT_BAND fails the test."""
+    A ray whose kernel `raysat` disagrees with the oracle's although its margin is >= SAT_BAND fails the test.
 
-    def __init__(self, ref_sat, margin, gout, max_frac=0.005, min_allowed=2):
+    The other discontinuity is the INCLUSION of a sample: the strict box test and the march bound.  `edge` (optional;
+    Oracle.march_forward(ray_diagnostics=True)["edge"]) is the float64 oracle's own largest opacity increment among
+    the inclusion decisions that came within fp32 position round-off of flipping.  Rays with edge > EDGE_JUMP are
+    masked like the saturation-fragile ones (an fp32 march -- the reference's included -- may decide them either
+    way); that matters with fade parameters that leave a visible opacity AT the box faces (fadescale well below 8) or
+    very opaque slabs, and is nil for the reference's fade(8, 8) at ordinary opacities (e^-8 at the face)."""
+
+    def __init__(self, ref_sat, margin, gout, max_frac=0.005, min_allowed=2, edge=None):
         self.ref_sat, self.margin, self.gout = ref_sat, margin, gout
         self.max_frac, self.min_allowed = max_frac, min_allowed
+        self.edge_mask = None if edge is None else np.asarray(edge) > EDGE_JUMP
         self.mask = None
 
     def __call__(self, hip_raysat):
         diff = np.abs(hip_raysat - self.ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(self.ref_sat).max())
+        if self.edge_mask is not None:  # a ray that included one more / one fewer sample may also saturate elsewhere
+            diff = diff & ~self.edge_mask
         unjustified = diff & ~(self.margin < SAT_BAND)
         assert unjustified.sum() == 0, ("rays saturate differently from the oracle outside the %g band" % SAT_BAND,
                                         int(unjustified.sum()), float(self.margin[unjustified].min()))
         assert diff.sum() <= max(self.min_allowed, self.max_frac * diff.size), int(diff.sum())
-        self.mask = diff
+        self.mask = diff if self.edge_mask is None else (diff | self.edge_mask)
         return self.masked()
 
     def masked(self):
