@@ -194,6 +194,12 @@ def fuzz_draw(seed, oracle64):
     N = int(rng.integers(1, 4))
     H, W = int(rng.integers(9, 71)), int(rng.integers(9, 71))
     K = int(rng.choice([1, 2, 3, 7, 8, 33, 64, 100, 257, 512, 700]))
+    rng3 = np.random.default_rng(9000 + seed)
+    if seed >= 10 and rng3.random() < 0.2:
+        # few primitives under many packets: a primitive's list runs to hundreds of entries and tens of thousands of
+        # samples, i.e. several accumulation rounds per primitive, and lists beyond the first capacity guess
+        N, H, W = int(rng3.integers(1, 3)), int(rng3.integers(90, 181)), int(rng3.integers(90, 181))
+        K = int(rng3.choice([16, 33, 64, 100]))
     shape = tuple(int(x) for x in rng.integers(2, 10, size=3)) if rng.random() < 0.5 else (8, 8, 8)
     again = float(rng.choice([0.5, 2.0, 8.0, 30.0]))
     fadescale, fadeexp = (8.0, 8.0) if rng.random() < 0.5 else (float(rng.uniform(3, 9)), float(rng.uniform(2.5, 9)))
@@ -229,7 +235,7 @@ def fuzz_draw(seed, oracle64):
     return dict(N=N, K=K, args=a, fadescale=fadescale, fadeexp=fadeexp, mode=mode, warp=warp, gout=gout, gstyle=gstyle, cfg=cfg)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MVP_FUZZ_SEEDS", "10")))))  # more with MVP_FUZZ_SEEDS=n
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MVP_FUZZ_SEEDS", "24")))))  # more with MVP_FUZZ_SEEDS=n
 def test_randomized_configurations(ops, oracle64, oracle32, seed):
     """Seeded random draws over image size (ragged packets), primitive count (non powers of two, tiny), slab shape,
     opacity (none to most rays saturating), box size, step size and fade parameters, and -- one draw in four -- a warp
@@ -281,7 +287,7 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
                                       ("primrot", grads["primrot"], rgr, r32[1]), ("primscale", grads["primscale"], rgs, r32[2])):
                 e_k, e_32 = np.abs(mine - r64).max(), np.abs(f32 - r64).max()
                 tol = (GT_TOL if k == "template" else POSE_TOL) * np.abs(r64).max()
-                assert e_k <= max(tol, e_32), (cfg, k, "kernel", e_k, "fp32 oracle", e_32, "bound", tol)
+                assert e_k <= max(tol, 1.5 * e_32), (cfg, k, "kernel", e_k, "fp32 oracle", e_32, "bound", tol)
     if warp is not None:  # a position gradient like the pose gradients (see the warp-field tests below for the bounds)
         gw, rgw = grads["warp"], ref[4]
         assert cosine(gw, rgw) >= POSE_COS and np.linalg.norm(gw - rgw) <= 2e-2 * np.linalg.norm(rgw), (cfg, cosine(gw, rgw))
