@@ -20,12 +20,22 @@ def positional_encoding(samplecoords: torch.Tensor) -> torch.Tensor:
                      [torch.cos(2 ** i * math.pi * samplecoords) for i in range(10)], dim=-1)
 
 
+def _chunks(M: int, chunks: int = 64) -> int:
+    return chunks if M % chunks == 0 and M >= chunks * 256 else 1
+
+
 def _wgrad(dy: torch.Tensor, x: torch.Tensor, chunks: int = 64) -> torch.Tensor:
-    """dy^T @ x for tall bf16 matrices [M, a], [M, b] with the M-reduction split into `chunks` batched GEMMs whose
-    partial products are summed in fp32 (a 256 x 256 output with K = M gives hipBLASLt 16 workgroups otherwise)."""
-    M = dy.shape[0]
-    S = chunks if M % chunks == 0 and M >= chunks * 256 else 1
-    return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).float().sum(0)
+    """dy^T @ x for tall bf16 matrices [M, a], [M, b] -- or stacks of them [L, M, a], [L, M, b] -> [L, a, b] -- with the
+    M-reduction split into `chunks` batched GEMMs (a 256 x 256 output with K = M gives hipBLASLt 16 workgroups
+    otherwise).  ONE bmm call for the whole stack, partial products delivered in fp32 (`out_dtype`) and summed in fp32:
+    against four calls with bf16 partial products 0.76 instead of 1.20 ms at 4 x 512^2 pixels and 2e-7 instead of 1.7e-3
+    from float64 (tools/bench_wgrad.py, profiles/r03_wgrad_bench.txt)."""
+    stack = dy.dim() == 3
+    L, M = (dy.shape[0], dy.shape[1]) if stack else (1, dy.shape[0])
+    S = _chunks(M, chunks)
+    r = torch.bmm(dy.reshape(L * S, M // S, -1).transpose(1, 2), x.reshape(L * S, M // S, -1), out_dtype=torch.float32)
+    r = r.view(L, S, r.shape[-2], r.shape[-1]).sum(1)
+    return r if stack else r[0]
 
 
 class _FusedBgMlp(torch.autograd.Function):
@@ -76,12 +86,18 @@ class _FusedBgMlp(torch.autograd.Function):
                                                          ptr(colsum), stream_ptr(dev)), "mvp_bgmlp_backward")
         g_bias1 = colsum[0].sum(1)
         g_w1pos = _wgrad(dz[0], x0)[:, :POS]
-        g6 = (gout.view(B, 3, HW).permute(0, 2, 1).reshape(P, 3) * 25.0)
-        g_w6 = _wgrad(g6.to(torch.bfloat16), acts[HIDDEN])
-        g_b6 = g6.sum(0)
+        # last layer (mlp2d.py:69: output = MLP * 25 + 100).  gout is [B,3,HW]: its rows ARE the [3 x pixels] operand of the
+        # weight gradient, image by image, and the bias gradient is a sum over contiguous planes (the transposed [P,3]
+        # copy and its strided column sum cost 0.36 ms at 4 x 512^2)
+        S6 = _chunks(HW, 16)
+        g6 = (gout.view(B, 3, S6, HW // S6) * 25.0).to(torch.bfloat16).permute(0, 2, 1, 3).reshape(B * S6, 3, HW // S6)
+        g_w6 = torch.bmm(g6, acts[HIDDEN].view(B * S6, HW // S6, WIDTH), out_dtype=torch.float32).sum(0)
+        g_b6 = gout.sum((0, 2, 3)) * 25.0
+        g_wh = _wgrad(dz[1:], acts[:HIDDEN])
+        g_bh = colsum[1:].sum((1, 2))
         hidden = []
         for l in range(HIDDEN):
-            hidden += [_wgrad(dz[l + 1], acts[l]), colsum[l + 1].sum((0, 1))]
+            hidden += [g_wh[l], g_bh[l]]
         return (None, g_bias1, g_w1pos, g_w6, g_b6, *hidden)
 
 
