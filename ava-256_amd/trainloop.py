@@ -363,7 +363,11 @@ class Trainer:
                         bucket_cap_mb=bucket_cap_mb)
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.optim = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999))
+        # (the reference's torch.optim.Adam, ddp-train.py:78; on the GPU as ONE multi-tensor kernel instead of the ~10
+        #  foreach passes over every parameter -- the same update)
+        self.optim = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999),
+                                      fused=bool(self.params) and self.params[0].is_cuda)
+        self.ddp = ddp
         self.sched = torch.optim.lr_scheduler.StepLR(self.optim, step_size=lr_scheduler_iter, gamma=gamma)
         self.clip = clip
         self.loss_weights = dict(loss_weights or REFERENCE_LOSS_WEIGHTS)  # configs/config.yaml:17-21
@@ -398,7 +402,10 @@ class Trainer:
                             idindex=batch.get("idindex"), gt_verts=batch.get("verts"), noise=batch.get("noise"))
         losses = self.losses(output, batch)
         loss = self.total_loss(losses)
-        self.optim.zero_grad(set_to_none=False)
+        # single process: drop the gradients, so that backward hands each parameter its gradient tensor instead of
+        # zero-filling and then accumulating into it (two passes over every parameter saved); under DDP the gradients are
+        # views of the all-reduce bucket and stay where they are
+        self.optim.zero_grad(set_to_none=not self.ddp)
         loss.backward()
         # NaN / Inf -> 0 in every gradient, then clip the global 2-norm (ddp-train.py:436-441: two masked assignments
         # per tensor -- ~600 host syncs per iteration on ava-256 -- and clip_grad_norm_).  On the GPU both are two
