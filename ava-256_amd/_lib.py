@@ -30,9 +30,11 @@ SIGNATURES = {
                            [_c_void_p] * 2),
 }
 # N,H,W,K | campos,camrot,focal,princpt,pixelcoords | volradius,stepsize | nodeaabb,primpos,primrot,primscale | TD,TH,TW |
-# tplate,rayrgba,raysat,rayaux,primlist_count,primlist | primlist_cap | fadescale,fadeexp | diag,stream
+# tplate,rayrgba,raysat,rayaux,primlist_count,primlist | primlist_cap | raypos_out,raydir_out,tminmax_out |
+# fadescale,fadeexp | diag,stream
 SIGNATURES["mvp_march_forward_cams"] = (_c_int, [_c_int] * 4 + [_c_void_p] * 5 + [_c_float] * 2 + [_c_void_p] * 4 +
-                                        [_c_int] * 3 + [_c_void_p] * 6 + [_c_int] + [_c_float] * 2 + [_c_void_p] * 2)
+                                        [_c_int] * 3 + [_c_void_p] * 6 + [_c_int] + [_c_void_p] * 3 + [_c_float] * 2 +
+                                        [_c_void_p] * 2)
 SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
 # N,H,W | rayrgba | rayrgb,rayalpha | stream     and     N,H,W | g_rgb,g_alpha | g_rgba | stream
@@ -52,7 +54,7 @@ SIGNATURES["mvp_bgmlp_forward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 10 + [_c
 SIGNATURES["mvp_bgmlp_backward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 6 + [_c_void_p])
 # N, H, W, K, kind, first_block, count | out, total_blocks
 SIGNATURES["mvp_march_block_map"] = (_c_int, [_c_int] * 7 + [_c_void_p] * 2)
-ABI_VERSION = 9
+ABI_VERSION = 10
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -76,6 +76,8 @@ struct MarchParams {
     // with the arithmetic of raydirs_kernel (mvp_device.h: ray_from_camera) -- mvp_march_forward_cams
     const float *campos, *camrot, *focal, *princpt, *pixelcoords;
     float volradius;
+    // ... and, in grad mode, written out for the backward (all three or none): what mvp_raydirs_forward would have written
+    float *raypos_out, *raydir_out, *tminmax_out;
     int WD, WH, WW;                              // warp-field grid (algo 1), 0 when absent
     const float *warp;                           // [N,K,WD,WH,WW,3] or null
     float *grad_warp;                            // backward, algo 1
@@ -630,6 +632,12 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             const CamRay c = ray_from_camera(mk3(cload(cp), cload(cp + 1), cload(cp + 2)), p.camrot + (size_t)n * 9,
                                              cload(fo), cload(fo + 1), cload(pc2), cload(pc2 + 1), fpx, fpy, p.volradius);
             o = c.o, d = c.d, tmin = c.tmin, tmax = c.tmax;
+            if (p.raydir_out) {  // (wave-uniform) the backward's ray tensors, written by the packet that owns the pixel
+                float *po = p.raypos_out + r * 3, *pd = p.raydir_out + r * 3;
+                po[0] = o.x, po[1] = o.y, po[2] = o.z;
+                pd[0] = d.x, pd[1] = d.y, pd[2] = d.z;
+                reinterpret_cast<float2 *>(p.tminmax_out)[r] = make_float2(tmin, tmax);
+            }
         } else {
             const float *op = p.raypos + r * 3, *dp = p.raydir + r * 3, *tp = p.tminmax + r * 2;
             o = mk3(MVP_STREAM_LOADF(op), MVP_STREAM_LOADF(op + 1), MVP_STREAM_LOADF(op + 2));
@@ -2662,6 +2670,7 @@ static int march_common_checks(bool bwd, mvp::MarchParams &p) {
 struct CameraArgs {  // mvp_march_forward_cams: rays are made inside the march
     const float *campos, *camrot, *focal, *princpt, *pixelcoords;
     float volradius;
+    float *raypos_out, *raydir_out, *tminmax_out;  // all three or none
 };
 
 static int march_forward_impl(int N, int H, int W, int K, const float *raypos, const float *raydir, const CameraArgs *cams,
@@ -2675,7 +2684,11 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
     if (cams) {
         p.campos = cams->campos, p.camrot = cams->camrot, p.focal = cams->focal, p.princpt = cams->princpt;
         p.pixelcoords = cams->pixelcoords, p.volradius = cams->volradius;
+        p.raypos_out = cams->raypos_out, p.raydir_out = cams->raydir_out, p.tminmax_out = cams->tminmax_out;
         if (!p.campos) return MVP_ERR_BADARG;
+        const int nout = (p.raypos_out != nullptr) + (p.raydir_out != nullptr) + (p.tminmax_out != nullptr);
+        if (nout != 0 && nout != 3) return MVP_ERR_BADARG;
+        if (p.tminmax_out && ((uintptr_t)p.tminmax_out & 7u)) return MVP_ERR_BADARG;
     }
     p.N = N, p.H = H, p.W = W, p.K = K, p.TD = TD, p.TH = TH, p.TW = TW;
     p.WD = WD, p.WH = WH, p.WW = WW, p.warp = warp;
@@ -2750,9 +2763,10 @@ extern "C" int mvp_march_forward_cams(int N, int H, int W, int K, const float *c
                                       float volradius, float stepsize, const float *nodeaabb, const float *primpos,
                                       const float *primrot, const float *primscale, int TD, int TH, int TW,
                                       const float *tplate, float *rayrgba, float *raysat, uint32_t *rayaux,
-                                      uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale,
+                                      uint32_t *primlist_count, uint32_t *primlist, int primlist_cap,
+                                      float *raypos_out, float *raydir_out, float *tminmax_out, float fadescale,
                                       float fadeexp, uint32_t *diag, void *stream) {
-    const CameraArgs cams = {campos, camrot, focal, princpt, pixelcoords, volradius};
+    const CameraArgs cams = {campos, camrot, focal, princpt, pixelcoords, volradius, raypos_out, raydir_out, tminmax_out};
     return march_forward_impl(N, H, W, K, nullptr, nullptr, &cams, stepsize, nullptr, nodeaabb, primpos, primrot,
                               primscale, TD, TH, TW, tplate, 0, 0, 0, nullptr, rayrgba, raysat, rayaux, primlist_count,
                               primlist, primlist_cap, fadescale, fadeexp, diag, stream);

@@ -175,11 +175,15 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
                 ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp, ptr(_hooks.diag),
                 stream_ptr(dev)), "mvp_march_forward")
         else:
+            if gradmode:  # the backward's ray tensors: written by the forward march itself (no raydirs launch)
+                raypos = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
+                raydir = torch.empty((N, H, W, 3), device=dev, dtype=torch.float32)
+                tminmax = torch.empty((N, H, W, 2), device=dev, dtype=torch.float32)
             _lib.check(_lib.get_lib().mvp_march_forward_cams(
                 N, H, W, K, ptr(campos), ptr(camrot), ptr(focal), ptr(princpt), ptr(pc), float(volradius),
                 float(stepsize), ptr(nodeaabb), ptr(primpos), ptr(primrot), ptr(primscale), TD, TH, TW, ptr(template),
-                ptr(rayrgba), ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, fadescale, fadeexp,
-                ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_forward_cams")
+                ptr(rayrgba), ptr(raysat), ptr(rayaux), ptr(pl_count), ptr(pl_list), pl_cap, ptr(raypos), ptr(raydir),
+                ptr(tminmax), fadescale, fadeexp, ptr(_hooks.diag), stream_ptr(dev)), "mvp_march_forward_cams")
 
     if pl_count is not None:
         with torch.cuda.device(dev):
@@ -187,14 +191,9 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
     if _hooks.keep_raysat:
         _hooks.last_raysat = raysat
         _hooks.last_pl_count = pl_count
-    if cams is None:
-        ctx.cams = None
-        ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
-                              pl_count, pl_list, warp)
-    else:  # the backward takes ray tensors: they are made there, only if a backward happens
-        ctx.cams = (pc is None, (W, H), float(volradius))
-        ctx.save_for_backward(campos, camrot, focal, princpt, pc, nodeaabb, primpos, primrot, primscale, template,
-                              raysat, rayaux, pl_count, pl_list)
+    # (camera form in grad mode: raypos / raydir / tminmax are the tensors the forward march has just written)
+    ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
+                          pl_count, pl_list, warp)
     ctx.pl_cap = pl_cap
     ctx.options = options
     ctx.stepsize = float(stepsize)
@@ -202,17 +201,8 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
 
 
 def _backward_impl(ctx, grad_rayrgba):
-    if ctx.cams is None:
-        (raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux, pl_count,
-         pl_list, warp) = ctx.saved_tensors
-    else:
-        (campos, camrot, focal, princpt, pc, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
-         pl_count, pl_list) = ctx.saved_tensors
-        warp = None
-        if raysat is not None:
-            from .raydirs import compute_raydirs
-            nopc, wh, volradius = ctx.cams
-            raypos, raydir, tminmax = compute_raydirs(campos, camrot, focal, princpt, wh if nopc else pc, volradius)
+    (raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux, pl_count,
+     pl_list, warp) = ctx.saved_tensors
     if raysat is None:
         raise RuntimeError("backward through mvpraymarch needs grad mode enabled during the forward call")
     fadescale, fadeexp = float(ctx.options["fadescale"]), float(ctx.options["fadeexp"])
@@ -258,7 +248,9 @@ class MVPRaymarch(Function):
 
 class MVPRaymarchFromCameras(Function):
     """The same operator with the rays made inside the march kernel (mvp_march_forward_cams): the caller's
-    compute_raydirs + mvpraymarch pair (models/autoencoder.py:240-252) as one call, no ray tensors in HBM."""
+    compute_raydirs + mvpraymarch pair (models/autoencoder.py:240-252) as one call.  Without gradients no ray tensor
+    exists in HBM; in grad mode the forward march writes the rays it made for the backward (what compute_raydirs would
+    have written), so a training step has no raydirs launch and its forward reads no ray tensor."""
 
     @staticmethod
     def forward(ctx, campos, camrot, focal, princpt, pixelcoords, volradius, stepsize, primpos, primrot, primscale,

@@ -77,8 +77,9 @@ class Raymarcher(nn.Module):
                              renderoptions: Optional[dict] = {}):
         """The caller's two statements -- compute_raydirs(campos, camrot, focal, princpt, pixelcoords, volume_radius)
         then forward(raypos, raydir, tminmax, decout) (models/autoencoder.py:240-252) -- as one kernel pass: the rays
-        are made inside the march (mvp_march_forward_cams), bit-identical to the two-call form, and never touch HBM.
-        Optional extension; the drop-in path is forward()."""
+        are made inside the march (mvp_march_forward_cams), bit-identical to the two-call form.  Rendering: no ray
+        tensor touches HBM.  Training: the forward march writes the rays once, for its backward -- no raydirs launch,
+        no ray reads in the forward.  Optional extension; the drop-in path is forward()."""
         opts = {k: v for k, v in (renderoptions or {}).items() if k in _OPTION_NAMES}
         prims = (decout["primpos"], decout["primrot"], decout["primscale"])
         rayrgba = mvpraymarch_from_cameras(campos, camrot, focal, princpt, pixelcoords, self.volume_radius, self.dt,

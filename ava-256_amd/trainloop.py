@@ -25,7 +25,7 @@ the conv decoder would be:
                        one-hot MLPs -> 40 + 40 channels, 40 positional-encoding channels, 1x1 convs 120 -> 256 x 5 -> 3,
                        output * 25 + 100), run under torch.autocast(bfloat16) on the GPU: the one genuinely dense
                        contraction next to the raymarch (154 GFLOP per 512^2 image), i.e. where MFMA belongs.
-  RaymarchTrainModel   decoder -> compute_raydirs -> Raymarcher -> colour calibration -> background -> matting
+  RaymarchTrainModel   decoder -> rays + Raymarcher (one call, or the reference's two) -> colour calibration -> background -> matting
                        `rayrgb + (1 - rayalpha) * bg`, the tail of Autoencoder.decode (models/autoencoder.py:240-269).
   Trainer              the loop body with the reference's semantics and hyper-parameters (configs/config.yaml:9-21).
 
@@ -304,8 +304,9 @@ class RaymarchTrainModel(nn.Module):
 
     def __init__(self, decoder: nn.Module, volradius: float = 256.0, dt: float = 1.0,
                  renderer: Optional[Callable] = None, colorcal: Optional[nn.Module] = None,
-                 bgmodel: Optional[nn.Module] = None, encoder: Optional[nn.Module] = None):
+                 bgmodel: Optional[nn.Module] = None, encoder: Optional[nn.Module] = None, fused_rays: bool = True):
         super().__init__()
+        self.fused_rays = fused_rays  # rays made inside the forward march instead of the two statements
         self.decoder = decoder
         self.encoder = encoder
         self.raymarcher = Raymarcher(volradius, dt)
@@ -322,7 +323,9 @@ class RaymarchTrainModel(nn.Module):
         decout = self.decoder(code, schedule=schedule, gt_geo=gt_verts)
         if self._renderer is not None:
             rayrgb, rayalpha = self._renderer(camrot, campos, focal, princpt, pixelcoords, decout)
-        else:
+        elif self.fused_rays and decout.get("warp") is None:
+            rayrgb, rayalpha, _, _ = self.raymarcher.forward_from_cameras(campos, camrot, focal, princpt, pixelcoords, decout)
+        else:                                                                        # autoencoder.py:240-252 as written
             raypos, raydir, tminmax = compute_raydirs(campos, camrot, focal, princpt, pixelcoords,
                                                       self.raymarcher.volume_radius)
             rayrgb, rayalpha, _, _ = self.raymarcher(raypos, raydir, tminmax, decout)

@@ -193,13 +193,23 @@ def make_march_step_gpu(args, rank, world, dev):
         rgba.backward(gout)
         return rgba
 
+    def fused_step():  # the same training step with the rays made inside the forward march (row N1): no raydirs launch
+        for k in prim_names:
+            s[k].grad = None
+        rgba = ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"],
+                                            volradius, stepsize, (s["primpos"], s["primrot"], s["primscale"]),
+                                            s["template"])
+        rgba.backward(gout)
+        return rgba
+
     def render():  # inference: no gradients, rays made inside the march (row N1), nothing handed to a backward
         with torch.no_grad():
             return ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"],
                                                 volradius, stepsize, (s["primpos"], s["primrot"], s["primscale"]),
                                                 s["template"])
 
-    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render}
+    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render,
+                  "fused_step": fused_step}
 
 
 def kernel_averages(events):
@@ -347,6 +357,17 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         ev1.record()
         torch.cuda.synchronize(dev)
         render_ms = ev0.elapsed_time(ev1) / 5
+    fused_ms = None
+    if gpu and "fused_step" in info and not args.no_render:  # the training step with row N1's fusion (extra field as well)
+        for _ in range(2):
+            info["fused_step"]()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            info["fused_step"]()
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        fused_ms = ev0.elapsed_time(ev1) / 5
 
     # rays of all ranks per step: every rank contributes its own shard (gathered, so that uneven strong-scaling
     # shards are counted exactly)
@@ -418,6 +439,10 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             if render_ms is not None:
                 out["render"] = {"what": "no-grad forward with rays made inside the march (mvp_march_forward_cams), this rank",
                                  "ms": render_ms, "rays_per_s": info["n_local"] * H * W / (render_ms * 1e-3)}
+            if fused_ms is not None:
+                out["fused_rays_step"] = {"what": "the same training step with the rays made inside the forward march "
+                                                  "(mvpraymarch_from_cameras + backward: no raydirs launch), this rank",
+                                          "ms": fused_ms, "rays_per_s": info["n_local"] * H * W / (fused_ms * 1e-3)}
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_measured_at_commit": traffic_at,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 9
+#define MVP_ABI_VERSION 10
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -103,15 +103,19 @@ int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const flo
  * the two calls above).  Fuses compute_raydirs_forward_cuda (utils_kernel.cu:12-52) into raymarch_forward_cuda for the
  * caller models/autoencoder.py:240-252: no raypos / raydir / tminmax tensors are written or read (32 B per ray each
  * way).  The rays are bit-identical to mvp_raydirs_forward's (one shared statement of the arithmetic), hence so is
- * rayrgba.  pixelcoords may be NULL (integer pixel grid).  algo 0 only (no warp field).  The backward takes ray tensors:
- * a caller that needs gradients makes them then (mvp_raydirs_forward) and calls mvp_march_backward. */
+ * rayrgba.  pixelcoords may be NULL (integer pixel grid).  algo 0 only (no warp field).
+ * Training: mvp_march_backward takes ray tensors.  With raypos_out / raydir_out / tminmax_out ([N,H,W,3], [N,H,W,3],
+ * [N,H,W,2]; all three or all NULL) the forward writes the rays it made -- every pixel by the one packet that owns it,
+ * the bytes mvp_raydirs_forward would have written -- and the caller hands them to mvp_march_backward: the training
+ * step then has no raydirs launch and the forward reads no ray tensor. */
 int mvp_march_forward_cams(int N, int H, int W, int K, const float *campos /*[N,3]*/, const float *camrot /*[N,3,3]*/,
                            const float *focal /*[N,2]*/, const float *princpt /*[N,2]*/,
                            const float *pixelcoords /*[N,H,W,2] or NULL*/, float volradius, float stepsize,
                            const float *nodeaabb, const float *primpos, const float *primrot, const float *primscale,
                            int TD, int TH, int TW, const float *tplate, float *rayrgba, float *raysat, uint32_t *rayaux,
-                           uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale,
-                           float fadeexp, uint32_t *diag, void *stream);
+                           uint32_t *primlist_count, uint32_t *primlist, int primlist_cap,
+                           float *raypos_out /*or NULL*/, float *raydir_out /*or NULL*/, float *tminmax_out /*or NULL*/,
+                           float fadescale, float fadeexp, uint32_t *diag, void *stream);
 
 /* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
  * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are OVERWRITTEN (every element is written; the

@@ -274,11 +274,11 @@ def test_hit_list_cap_matches_the_reference_rule(ops, oracle64):
 
 @pytest.mark.parametrize("pixel_form", ["tensor", "tuple"])
 def test_fused_camera_entry_point_is_bit_identical(ops, pixel_form):
-    """SURVEY.md 8f row N1 (first half): mvp_march_forward_cams makes the rays inside the march.  One shared statement
-    of the ray arithmetic (mvp_device.h: ray_from_camera) => the image, raysat, and -- through a backward that makes the
-    ray tensors only then -- the slab gradient are IDENTICAL to compute_raydirs + mvpraymarch (pose gradients to fp32
-    round-off: their ray sums are not order-deterministic in either form).  Ragged image, both forms
-    of pixelcoords (extensions/utils/utils.py:28-33)."""
+    """mvp_march_forward_cams makes the rays inside the march.  One shared statement of the ray
+    arithmetic (mvp_device.h: ray_from_camera) => the image, raysat, the ray tensors the grad-mode forward writes for
+    its backward (every pixel of a ragged image, bit for bit what compute_raydirs writes) and the slab gradient are
+    IDENTICAL to compute_raydirs + mvpraymarch (pose gradients to fp32 round-off: their ray sums are not
+    order-deterministic in either form).  Both forms of pixelcoords (extensions/utils/utils.py:28-33)."""
     from ava256_amd.scene import make_scene
     N, H, W, K = 3, 83, 101, 512
     s = make_scene(N, H, W, K, device="cuda", seed=17, alpha_gain=8.0)
@@ -295,6 +295,8 @@ def test_fused_camera_entry_point_is_bit_identical(ops, pixel_form):
     t2 = {k: s[k].clone().requires_grad_(True) for k in names}
     b = ops.mvpraymarch_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], pc, s["volradius"], s["stepsize"],
                                      (t2["primpos"], t2["primrot"], t2["primscale"]), t2["template"])
+    saved = b.grad_fn.saved_tensors  # (raypos, raydir, tminmax, ...): written by the forward march, read by the backward
+    assert torch.equal(saved[0], rp) and torch.equal(saved[1], rd) and torch.equal(saved[2], tm)
     b.backward(gout)
     assert torch.equal(a, b)
     assert torch.equal(t1["template"].grad, t2["template"].grad)
