@@ -125,6 +125,61 @@ def test_config_sizes_against_oracle(cfg, oracle64, oracle32):
         assert np.abs(m - refg).max() <= 1e-1 * np.abs(refg).max()
 
 
+@pytest.mark.parametrize("style", ["outliers", "lognormal"])
+def test_c2_camera_with_heavy_tailed_upstream_gradients(style, oracle64):
+    """One camera of the bench workload (512^2, K=4096) with an upstream gradient whose magnitudes spread over decades
+    (0.1 % of the pixels at 1e4 x / per-pixel log-normal, sigma 3): the one-word fixed-point accumulators resolve a
+    round relative to the largest gradient near it, so this is where they could lose the primitives that only see small
+    ones.  Held: every primitive's slab gradient within 1e-3 of ITS OWN max |g| or within 1e-5 of the a-priori bound of
+    its values (at this image size the first holds for all but the primitives grazed at a corner), no
+    primitive pushed to the fp32-atomic fallback, the two-pass kernel in use, pose gradients cosine >= 0.9999."""
+    import ava256_amd as ops
+    from ava256_amd import _hooks
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 512, 512, 4096
+    s = make_scene(N, H, W, K, device="cpu", seed=1112, alpha_gain=2.0)
+    rp, rd, tm = scene_rays(oracle64, s)
+    a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
+    ref, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    rng = np.random.default_rng(4)
+    gout = rng.normal(size=ref.shape)
+    if style == "outliers":
+        gout[rng.random(size=ref.shape[:3]) < 1e-3] *= 1.0e4
+    else:
+        gout *= np.exp(3.0 * rng.normal(size=ref.shape[:3]))[..., None]
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in s.items()}
+    _hooks.keep_raysat = True
+    rp_d, rd_d, tm_d = ops.compute_raydirs(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"])
+    t = {k: d[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
+    rgba = ops.mvpraymarch(rp_d, rd_d, d["stepsize"], tm_d, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
+    hip_sat, handoff = npf(_hooks.last_raysat), _hooks.last_pl_count
+    _hooks.keep_raysat = False
+    _hooks.last_raysat = _hooks.last_pl_count = None
+    fragile = FragileRays(ref_sat, st["margin"], gout, edge=st["edge"])
+    g2 = fragile(hip_sat)
+    rgba.backward(torch.as_tensor(g2, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    cnt = handoff[: N * K].to(torch.int64) & 0xffffffff
+    flags, two_pass = int(handoff[N * K].item()), int(((cnt >> 30) & 1).sum().item())
+    assert flags & 7 == 0 and two_pass > 0 and flags & 8, (flags, two_pass)
+    gp, gr, gs, gt = oracle64.march_backward(*a, ref_sat, g2)
+    got, refk, tplk = npf(t["template"].grad).reshape(K, -1, 4), gt.reshape(K, -1, 4), a[7].reshape(K, -1, 4)
+    G, dt = np.abs(g2).max(), float(a[2])
+    Brgb = G * np.minimum(1.0, np.abs(tplk[..., 3]).max(1) * dt)
+    Ba = G * dt * (3.0 * (np.abs(tplk[..., :3]).max((1, 2)) + np.abs(tplk[..., :3]).max()) + 1.0)
+    e = np.abs(got - refk)
+    pm = np.abs(refk).max((1, 2))
+    rel = e.max((1, 2))[pm > 0] / pm[pm > 0]
+    print("C2 camera, %s: two-pass primitives %d of %d; per-primitive error / own max |g|: max %.2e, median %.2e, "
+          "share within 2e-4: %.4f; max|g| spread %.1e" % (style, two_pass, K, rel.max(), np.median(rel), (rel <= 2e-4).mean(),
+                                                           pm[pm > 0].max() / pm[pm > 0].min()))
+    for ek, pk, Bk in ((e[..., :3].max((1, 2)), np.abs(refk[..., :3]).max((1, 2)), Brgb), (e[..., 3].max(1), np.abs(refk[..., 3]).max(1), Ba)):
+        assert (ek - (1e-3 * pk + 1e-5 * Bk)).max() <= 0
+    assert (rel <= 1e-3).mean() >= 0.99
+    for mine, refg in ((t["primpos"].grad, gp), (t["primrot"].grad, gr), (t["primscale"].grad, gs)):
+        assert cosine(npf(mine), refg) >= 0.9999
+
+
 @pytest.mark.parametrize("cfg", [("C1smooth", 4, 128, 128, 512, 6.0), ("C3smooth", 1, 512, 512, 16384, 6.0)],
                          ids=lambda c: c[0])
 def test_smooth_templates_tight_pose_gradients(cfg, oracle64):
