@@ -1591,6 +1591,12 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 //   * a primitive whose list needs more than one round flushes the sums at the end of every round but the last into
 //     grad_template itself (every voxel has one owner thread, at every flush and at the end, so no atomics and no second
 //     LDS array; each flush converts with its round's scale) and restarts from zero.
+//   * ACCUMULATED ROUNDING.  Every add rounds to a quantum q_r = n_r B_r / 2^31, a cell receives ~8 n_r / V of them per
+//     round, so after the rounds r a cell's sum carries noise of about 0.29 / 2^31 * sqrt(8 / V * sum_r n_r^3) times the
+//     bound.  Ordinary primitives (C2: ~1200 samples, V = 512) sit at 1e-7 of the bound; a box that fills the image
+//     (tens of thousands of samples over several full rounds) reaches 2e-4 -- per-mille errors of ITS OWN gradient when
+//     the values are far below the bound.  A primitive whose sum_r n_r^3 passes kNoiseBudget * V (noise 3e-6 of the
+//     bound, rms) is therefore handed to the two-pass instantiation BEFORE the round that would pass it is marched.
 // The sums are exact integers, so a round's result does not depend on the order its samples arrive in.  The forward
 // appends list entries in a different order on every run; a multi-round primitive therefore walks its entries in
 // ascending packet order (a rank sort of the keys at kernel start, indices in LDS), which makes the composition of every
@@ -1619,6 +1625,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // 1024^2 prefers 3 (C4 1.90 vs 2.01 ms), C2 is indifferent; the host picks by packets per primitive.
 constexpr float kFixRange = 0.999f * 2147483648.f;  // |sum of a round's contributions * scale| stays below 2^31
 constexpr float kTwoPassRatio = 256.f;  // marched rays' gradient magnitudes further below the bound than this: two passes
+constexpr float kNoiseBudget = 6.2e7f;  // sum over rounds of (samples of the round)^3 per voxel: beyond it, two passes (header)
 constexpr int kRoundBudgetLog2 = 14;   // a round takes list entries while 64 lanes x their step ranges stay below 2^14
 #ifndef MVP_GRADPAD
 #define MVP_GRADPAD 5
@@ -1923,6 +1930,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         __syncthreads();
     };
     bool pass_b = false;  // this iteration re-marches the round it has just marched, for the residuals (workgroup-uniform)
+    float noise_cube = 0.f;  // sum over the rounds so far of (samples of the round)^3 (workgroup-uniform; header)
     for (uint32_t ebase = 0; ebase < cnt;) {
         if (tid < kLenBuckets) s_bucket[tid] = 0u;
         if (tid == 0) s_qn[1] = 0u, s_gext[0] = 0u, s_gext[1] = 0x7fffffffu;
@@ -2017,6 +2025,18 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             res_mul = kFixRange / (float)round_samples;
             s_rgb = uni(res_mul / Brgb), s_a = uni(res_mul / Ba);
             if constexpr (WARP) s_w = uni(res_mul / fmaxf(Bw, 1.0e-30f));
+        }
+        if constexpr (!RESID) {
+            // (rare: header, ACCUMULATED ROUNDING) this round would take the sums' rounding noise past the budget: the
+            // two-pass instantiation owns the primitive and overwrites every output (workgroup-uniform exit)
+            if (!pass_b) noise_cube += (float)round_samples * (float)round_samples * (float)round_samples;
+            if (noise_cube > kNoiseBudget * (float)V && s_qn[2] == 0u && !bad_bound) {
+                if (tid == 0) {
+                    atomicOr(p.pl_count + pk, kCountPrecise);
+                    raise_flag(tail, kFlagBwdPrecise);
+                }
+                return;
+            }
         }
         // a ray crosses this box over more than 127 steps, a sample weight left its bound in an earlier round (signed
         // opacity), or the upstream gradient / the slab is not finite: not this kernel's case

@@ -235,7 +235,8 @@ def fuzz_draw(seed, oracle64):
     return dict(N=N, K=K, args=a, fadescale=fadescale, fadeexp=fadeexp, mode=mode, warp=warp, gout=gout, gstyle=gstyle, cfg=cfg)
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MVP_FUZZ_SEEDS", "24")))))  # more with MVP_FUZZ_SEEDS=n
+@pytest.mark.parametrize("seed", [int(os.environ.get("MVP_FUZZ_FIRST", "0")) + i  # more draws: MVP_FUZZ_SEEDS=n, from
+                                  for i in range(int(os.environ.get("MVP_FUZZ_SEEDS", "24")))])  # seed MVP_FUZZ_FIRST on
 def test_randomized_configurations(ops, oracle64, oracle32, seed):
     """Seeded random draws over image size (ragged packets), primitive count (non powers of two, tiny), slab shape,
     opacity (none to most rays saturating), box size, step size and fade parameters, and -- one draw in four -- a warp
@@ -268,9 +269,17 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
         Ba = G * dt * (3.0 * (np.abs(tplk[..., :3]).max((1, 2)) + np.abs(tplk[..., :3]).max()) + 1.0)
         e = np.abs(grads["template"].reshape(N * K, -1, 4) - rgt.reshape(N * K, -1, 4))
         pmax = np.abs(rgt.reshape(N * K, -1, 4))
-        for name, ek, pk, Bk in (("rgb", e[..., :3].max((1, 2)), pmax[..., :3].max((1, 2)), Brgb),
-                                 ("alpha", e[..., 3].max(1), pmax[..., 3].max(1), Ba)):
+        e32 = None
+        for name, ek, pk, Bk, ch in (("rgb", e[..., :3].max((1, 2)), pmax[..., :3].max((1, 2)), Brgb, slice(0, 3)),
+                                     ("alpha", e[..., 3].max(1), pmax[..., 3].max(1), Ba, slice(3, 4))):
             over = ek - (GT_TOL * pk + 1e-5 * Bk)
+            if over.max() > 0:
+                # as below: acceptable only where plain fp32 (the oracle's f32 build, same raysat and gradients) is
+                # further from float64 on that very primitive (huge boxes: hundreds of samples per ray and primitive)
+                if e32 is None:
+                    r32 = oracle32.march_backward(*a, ref_sat, g2, fadescale=fadescale, fadeexp=fadeexp, warp=warp)
+                    e32 = np.abs(r32[3].reshape(N * K, -1, 4) - rgt.reshape(N * K, -1, 4))
+                over = ek - np.maximum(GT_TOL * pk + 1e-5 * Bk, 1.5 * e32[..., ch].max((1, 2)))
             assert over.max() <= 0, (cfg, "per-primitive template " + name, int(over.argmax()), float(ek[over.argmax()]),
                                      float(pk[over.argmax()]), float(Bk[over.argmax()]))
         for k, refg in (("primpos", rgp), ("primrot", rgr), ("primscale", rgs)):
