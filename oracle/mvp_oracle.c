@@ -286,6 +286,24 @@ void mvpo_set_edge_diagnostics(real *edge, real eps) {
     g_edge_eps = eps;
 }
 
+/* |opacity increment| of a sample taken at box coordinate y pulled just inside the box (edge diagnostic only) */
+static real edge_increment(const real *y, const real *Tk, int TD, int TH, int TW, const real *Wk, int WD, int WH, int WW,
+                           real fadescale, real fadeexp, real stepsize) {
+    real yc[3];
+    for (int j = 0; j < 3; ++j) yc[j] = rmin(rmax(y[j], (real)-0.999999), (real)0.999999);
+    real y1c[3] = {yc[0], yc[1], yc[2]};
+    if (Wk) {
+        tri_t tw;
+        tri_setup(WD, WH, WW, yc, &tw);
+        tri_fetch(Wk, 3, &tw, y1c);
+    }
+    tri_t trc;
+    tri_setup(TD, TH, TW, y1c, &trc);
+    real vc[4];
+    tri_fetch(Tk, 4, &trc, vc);
+    return R_ABS(vc[3] * fade_of(yc, fadescale, fadeexp) * stepsize);
+}
+
 /* warp may be NULL (algo 0).  With a warp field [N,K,WD,WH,WW,3] the template is sampled at y1 = warp(y0)
  * (PrimSamplerTW<true>, primsampler.h:53-58); the fade still uses y0. */
 int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const real *raydir, real stepsize,
@@ -339,21 +357,10 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
                             real smax = rmax(R_ABS(sc[0]), rmax(R_ABS(sc[1]), R_ABS(sc[2])));
                             int near_box = R_ABS(cheb - (real)1) < g_edge_eps * smax;
                             int near_t = R_ABS(t - (rtmax + (real)1e-5)) < g_edge_eps && cheb < (real)1 + g_edge_eps * smax;
-                            if (near_box || near_t) {
-                                real yc[3];
-                                for (int j = 0; j < 3; ++j) yc[j] = rmin(rmax(s.y[j], (real)-0.999999), (real)0.999999);
-                                real y1c[3] = {yc[0], yc[1], yc[2]};
-                                if (warp) {
-                                    tri_t tw;
-                                    tri_setup(WD, WH, WW, yc, &tw);
-                                    tri_fetch(warp + ((size_t)n * K + k) * VW * 3, 3, &tw, y1c);
-                                }
-                                tri_t trc;
-                                tri_setup(TD, TH, TW, y1c, &trc);
-                                real vc[4];
-                                tri_fetch(T + (size_t)k * V * 4, 4, &trc, vc);
-                                edge = rmax(edge, R_ABS(vc[3] * fade_of(yc, fadescale, fadeexp) * stepsize));
-                            }
+                            if (near_box || near_t)
+                                edge = rmax(edge, edge_increment(s.y, T + (size_t)k * V * 4, TD, TH, TW,
+                                                                 warp ? warp + ((size_t)n * K + k) * VW * 3 : NULL, WD, WH,
+                                                                 WW, fadescale, fadeexp, stepsize));
                         }
                         if (srt_valid(s.y) && !sat && t < rtmax + (real)1e-5) {
                             st2 += 1;
@@ -391,6 +398,22 @@ int mvpo_march_forward(int N, int H, int W, int K, const real *raypos, const rea
                     }
                     t += stepsize; /* subset_kernel.h:95-96: incremental adds */
                     for (int j = 0; j < 3; ++j) x[j] += d[j] * stepsize;
+                }
+                /* diagnostics only: the first step the march bound EXCLUDED, if it was excluded by less than eps (a box
+                 * whose exit sits that close behind the step would have included it) */
+                if (g_edge && !sat && t - (rtmax + (real)1e-5) < g_edge_eps) {
+                    for (int ks = 0; ks < nh; ++ks) {
+                        int k = hits[ks];
+                        const real *sc = ps + (size_t)k * 3;
+                        srt_t s;
+                        srt_forward(pp + (size_t)k * 3, pr + (size_t)k * 9, sc, x, &s);
+                        real cheb = rmax(R_ABS(s.y[0]), rmax(R_ABS(s.y[1]), R_ABS(s.y[2])));
+                        real smax = rmax(R_ABS(sc[0]), rmax(R_ABS(sc[1]), R_ABS(sc[2])));
+                        if (cheb < (real)1 + g_edge_eps * smax)
+                            edge = rmax(edge, edge_increment(s.y, T + (size_t)k * V * 4, TD, TH, TW,
+                                                             warp ? warp + ((size_t)n * K + k) * VW * 3 : NULL, WD, WH,
+                                                             WW, fadescale, fadeexp, stepsize));
+                    }
                 }
             }
             st5 += sat;

@@ -118,3 +118,35 @@ def test_boundary_fixture_is_the_oracle_behind_the_reference_glue(oracle64):
     # with the default fadescale the image differs: the option really went through the filter
     rgba8, _, _ = oracle64.march_forward(*args, fadescale=8.0, fadeexp=8.0)
     assert np.abs(rgba8 - rgba).max() > 1e-3
+
+
+def test_oracle_edge_diagnostic(oracle64):
+    """The per-ray `edge` diagnostic (mvp_oracle.c, mvpo_set_edge_diagnostics): the opacity increment at stake in the
+    sample-inclusion decisions (strict box test, march bound) that came within `edge_eps` world units of flipping.  It
+    never changes the render; it is zero when no decision is close (eps 0), grows with eps, is bounded by the largest
+    possible increment, and is what an eps-sized displacement of the boxes can change in a ray's opacity."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(1, 40, 36, 24, device="cpu", seed=4, alpha_gain=6.0, slab=4)
+    rp, rd, tm = oracle64.raydirs(s["campos"].numpy(), s["camrot"].numpy(), s["focal"].numpy(), s["princpt"].numpy(),
+                                  s["pixelcoords"].numpy(), s["volradius"])
+    a = (rp, rd, float(s["stepsize"]), tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(),
+         s["template"].numpy())
+    fade = dict(fadescale=3.0, fadeexp=4.0)  # e^-3 of the opacity is still there AT a box face
+    plain, _, _ = oracle64.march_forward(*a, **fade)
+    res = {}
+    for eps in (0.0, 1e-4, 1e-2):
+        rgba, _, st = oracle64.march_forward(*a, ray_diagnostics=True, edge_eps=eps, **fade)
+        assert np.array_equal(rgba, plain)
+        res[eps] = st["edge"]
+    assert res[0.0].max() == 0.0
+    assert (res[1e-4] <= res[1e-2]).all() and res[1e-2].max() > 0.0
+    amax = np.abs(a[7][..., 3]).max() * a[2]
+    assert res[1e-2].max() <= amax * (1 + 1e-12)
+    # moving every box by less than eps flips only decisions the diagnostic has flagged: a ray whose alpha changes by
+    # more than the smooth variation allows must carry edge > 0 at that eps
+    shift = a[4] + 2e-5 * np.array([1.0, -1.0, 0.5])
+    moved, _, _ = oracle64.march_forward(a[0], a[1], a[2], a[3], shift, *a[5:], **fade)
+    jump = np.abs(moved[..., 3] - plain[..., 3])
+    smooth = 2e-3 * np.maximum(plain[..., 3], 1e-3)   # d(alpha)/d(position) * 2e-5 stays far below this
+    flagged = res[1e-4] > 0
+    assert not (jump > smooth)[~flagged].any(), int((jump > smooth)[~flagged].sum())
