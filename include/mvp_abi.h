@@ -99,7 +99,7 @@ int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const flo
                       uint32_t *primlist_count, uint32_t *primlist, int primlist_cap, float fadescale, float fadeexp,
                       uint32_t *diag, void *stream);
 
-/* Forward march with the rays made inside the kernel (first half; optional -- the drop-in path is
+/* Forward march with the rays made inside the kernel (optional -- the drop-in path is
  * the two calls above).  Fuses compute_raydirs_forward_cuda (utils_kernel.cu:12-52) into raymarch_forward_cuda for the
  * caller models/autoencoder.py:240-252: no raypos / raydir / tminmax tensors are written or read (32 B per ray each
  * way).  The rays are bit-identical to mvp_raydirs_forward's (one shared statement of the arithmetic), hence so is
