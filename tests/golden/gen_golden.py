@@ -211,6 +211,8 @@ if __name__ == "__main__":
     save_march("march_k64_m4", N=2, H=13, W=13, k3=4, M=4, fadescale=8.0, fadeexp=8.0)
     # dense opacity: most rays saturate -> exercises the raysat backward rule (primaccum.h:86-93)
     save_march("march_k8_m8_sat", N=1, H=15, W=15, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0)
+    # K = 125: not a power of two (leaves on two levels of the implicit heap), general fade (pow / exp path), thin opacity
+    save_march("march_k125_m4_fade", N=1, H=13, W=13, k3=5, M=4, fadescale=4.0, fadeexp=3.0, alpha_shift=6.0)
     # warp-field sampler (mvpraymarch.py:762-774: dowarp=True, algo=1), warp grid M/2
     save_march("march_warp_k8_m8", N=2, H=15, W=15, k3=2, M=8, fadescale=6.5, fadeexp=7.5, dowarp=True)
     save_march("march_warp_k8_m8_sat", N=1, H=13, W=13, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0,

@@ -99,7 +99,7 @@ def _check_grads(mine, ref, what=""):
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", BACKWARD_MODES)
-@pytest.mark.parametrize("name", ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat"])
+@pytest.mark.parametrize("name", ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat", "march_k125_m4_fade"])
 def test_march_matches_reference_golden(ops, name, mode):
     """HIP forward + backward vs the fixtures made from mvpraymarch.py:553-641 (float64)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -12,7 +12,7 @@ import pytest
 
 from conftest import GOLDEN
 
-MARCH = ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat", "march_warp_k8_m8", "march_warp_k8_m8_sat"]
+MARCH = ["march_k8_m8", "march_k64_m4", "march_k8_m8_sat", "march_k125_m4_fade", "march_warp_k8_m8", "march_warp_k8_m8_sat"]
 
 
 def _run(o, g):
