@@ -54,7 +54,9 @@ SIGNATURES["mvp_bgmlp_forward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 10 + [_c
 SIGNATURES["mvp_bgmlp_backward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 6 + [_c_void_p])
 # N, H, W, K, kind, first_block, count | out, total_blocks
 SIGNATURES["mvp_march_block_map"] = (_c_int, [_c_int] * 7 + [_c_void_p] * 2)
-ABI_VERSION = 10
+# primlist_count, nprims | hist[257] | stream
+SIGNATURES["mvp_list_demand"] = (_c_int, [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p])
+ABI_VERSION = 11
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -653,6 +653,12 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     f3 raysat = mk3(-1.f, -1.f, -1.f);
     uint32_t satkey = kNoSat;  // (step << 9) | list slot of the saturating sample
     float wbefore = 0.f;       // alpha just before it
+    // A NaN opacity sample (a diverged decoder).  primaccum.h:66-67: fminf(NaN, 1) = 1, so the forward fills alpha up to 1 and
+    // saturates at the NEXT sample -- while the reference's backward recomputes the prefix, gets NaN, never sees "saturated"
+    // and gives every later sample of the ray the unsaturated weight (primaccum.h:86-95).  The forward's record cannot
+    // express that; the packet raises the global flag instead and the ray-centric kernel, which recomputes the prefix the
+    // same way, owns this backward (slow, exact; the loop zeroes such gradients anyway, ddp-train.py:436-439).
+    bool nanw = false;
     int nh = 0;            // final list length (wave-uniform)
     int ncand = 0;
     bool fast = false;     // wave-uniform: this packet is marched by the lane-independent sweep
@@ -1103,6 +1109,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             else
                                 v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale, p.fadeexp);
                             float contrib;
+                            nanw = nanw || (v.w != v.w);
                             if (composite(rgba, v, dt, contrib)) {  // saturated: nothing after this sample is evaluated
                                 raysat = mk3(v.x, v.y, v.z);
                                 satkey = ((uint32_t)s << 9) | (uint32_t)slot;
@@ -1199,6 +1206,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                                                                p.fadeexp);
                                 }
                                 float contrib;
+                                nanw = nanw || (v.w != v.w);
                                 if (composite(rgba, v, dt, contrib)) {
                                     raysat = mk3(v.x, v.y, v.z);
                                     sat = true;
@@ -1499,6 +1507,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         float m = inimg ? fmaxf(fabsf(raysat.x), fmaxf(fabsf(raysat.y), fabsf(raysat.z))) : 0.f;
         if (!(m == m)) m = INFINITY;
         m = uni(wave_max(m));
+        if (__ballot(nanw) != 0ull && lane == 0) raise_flag(p.pl_count + (size_t)p.N * K, kFlagGlobal);
         if (m > 1.0f) {
             uint32_t *word = p.pl_count + (size_t)p.N * K + 2;
             const float cur = __uint_as_float(__atomic_load_n(word, __ATOMIC_RELAXED));  // stale is fine: monotone
@@ -1677,6 +1686,8 @@ __global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict
     }
 }
 
+__device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
 // float -> int, round to nearest (ties up): v_cvt_rpi_i32_f32.  (int)x truncates toward zero, a systematic shrink of
 // every contribution by half a unit on average.
 __device__ __forceinline__ int fix_rn(float v) {
@@ -1763,6 +1774,9 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     if (dead && (flags & kFlagGlobal) == 0u && !RESID) want_ray_centric();  // (list overflow; the global flag marches all)
 
     // ---- stage the slab with its max |rgb| and max |opacity|; longest step range on the list ----
+    // (as bit patterns of |x|: non-negative floats order like uints and a NaN's pattern is above Inf's, so ONE non-finite
+    //  voxel makes the bound non-finite -- fmaxf would drop a NaN and the integer sums would turn its contributions into zeros)
+    uint32_t tmaxb = 0u, amaxb = 0u;
     float tmax = 0.f, amax = 0.f;
     uint32_t maxlen = 1u;  // longest packet step range on the list (a ray's own range is inside its packet's)
     if (!dead && cnt > 0u) {
@@ -1780,15 +1794,15 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
 #pragma unroll
             for (int i = 0; i < kVoxPerThread; ++i) {
                 if (tid + i * kPrimBlock < 512) s_T[tid + i * kPrimBlock] = tv[i];
-                tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(tv[i].x), fabsf(tv[i].y)), fabsf(tv[i].z)));
-                amax = fmaxf(amax, fabsf(tv[i].w));
+                tmaxb = max(tmaxb, max(max(abs_bits(tv[i].x), abs_bits(tv[i].y)), abs_bits(tv[i].z)));
+                amaxb = max(amaxb, abs_bits(tv[i].w));
             }
         } else {
             for (int v = tid; v < V; v += kPrimBlock) {
                 const float4 t = T4[v];
                 s_T[v] = t;
-                tmax = fmaxf(tmax, fmaxf(fabsf(t.x), fmaxf(fabsf(t.y), fabsf(t.z))));
-                amax = fmaxf(amax, fabsf(t.w));
+                tmaxb = max(tmaxb, max(max(abs_bits(t.x), abs_bits(t.y)), abs_bits(t.z)));
+                amaxb = max(amaxb, abs_bits(t.w));
             }
         }
         {  // clear the sums: 4 * Vp words from a 16-byte aligned base, 16-byte stores
@@ -1797,10 +1811,11 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             for (int v = tid; v < nz4; v += kPrimBlock) z4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int v = (nz4 << 2) + tid; v < 4 * Vp; v += kPrimBlock) s_acc[v] = 0;
         }
-        tmax = wave_max(tmax);
-        amax = wave_max(amax);
+        tmaxb = (uint32_t)wave_max((int)tmaxb);  // (patterns < 2^31: signed order)
+        amaxb = (uint32_t)wave_max((int)amaxb);
         maxlen = (uint32_t)wave_max((int)maxlen);
-        if (lane == 0) s_red[wave] = tmax, s_red[8 + wave] = amax, s_red[12 + wave] = __uint_as_float(maxlen);
+        if (lane == 0)
+            s_red[wave] = __uint_as_float(tmaxb), s_red[8 + wave] = __uint_as_float(amaxb), s_red[12 + wave] = __uint_as_float(maxlen);
     }
     __syncthreads();
     // What the bounds of a round's contributions are made of, besides the round's own max |grad_rayrgba| G_q (header):
@@ -1810,10 +1825,12 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     //         +-w_y w_z (value_c . dLs) with sum |w_y w_z| <= 2, |value_c . dLs| <= (3 Tmax wrgb + Amax fa) G_q
     float wmax = 1.f, wrgb = 1.f, fa = 1.f, fw = 1.f;
     if (!dead && cnt > 0u) {
-        tmax = s_red[0], amax = s_red[8], maxlen = __float_as_uint(s_red[12]);
+        tmaxb = __float_as_uint(s_red[0]), amaxb = __float_as_uint(s_red[8]), maxlen = __float_as_uint(s_red[12]);
 #pragma unroll
         for (int w = 1; w < kPrimWaves; ++w)
-            tmax = fmaxf(tmax, s_red[w]), amax = fmaxf(amax, s_red[8 + w]), maxlen = max(maxlen, __float_as_uint(s_red[12 + w]));
+            tmaxb = max(tmaxb, __float_as_uint(s_red[w])), amaxb = max(amaxb, __float_as_uint(s_red[8 + w])),
+            maxlen = max(maxlen, __float_as_uint(s_red[12 + w]));
+        tmax = __uint_as_float(tmaxb), amax = __uint_as_float(amaxb);
         const float Rmax = __uint_as_float(cload(tail + 2));
         wmax = fminf(1.f, amax * p.stepsize * 1.0001f);
         // (a fully transparent slab -- relu(alpha) = 0 everywhere -- has wmax = 0: its rgb contributions are exact zeros and
@@ -1821,7 +1838,8 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         wrgb = fmaxf(wmax, 9.5367431640625e-07f);
         fa = p.stepsize * (3.f * (tmax + Rmax) + 1.f);
         if constexpr (WARP) fw = (float)(max(TD, max(TH, TW)) - 1) * (3.f * tmax * wrgb + amax * fa);
-        if (!(fa < 1.0e30f) || !(fw < 1.0e30f)) {  // non-finite slab / raysat: the ray-centric kernel's case
+        // non-finite slab (a NaN / Inf voxel in any channel) / raysat: the ray-centric kernel's case
+        if (!(fa < 1.0e30f) || !(fw < 1.0e30f) || !(amax < 1.0e30f)) {
             dead = true;
             want_ray_centric();
             if (tid == 0) {

@@ -18,42 +18,77 @@ from ._tensors import aligned, ptr, require_device_f32, stream_ptr
 
 class _ListDemand:
     """What the forward's per-primitive counters said the lists of one problem shape need (they keep counting past the
-    capacity): the high-water mark, and one measurement in flight (device max -> pinned word -> event)."""
-    __slots__ = ("hwm", "word", "event")
+    capacity): a decaying estimate of the wanted capacity, the capacity in use, and one measurement in flight (device
+    histogram -> pinned words -> event)."""
+    __slots__ = ("demand", "cap", "hist", "words", "event")
 
     def __init__(self):
-        self.hwm, self.word, self.event = 0, None, None
+        self.demand, self.cap, self.hist, self.words, self.event = 0.0, 0, None, None, None
 
     def poll(self):
         if self.event is not None and self.event.query():
-            self.hwm = max(self.hwm, int(self.word[0]))
+            self.note(wanted_from_histogram(self.words.tolist()))
             self.event = None
+
+    def note(self, wanted):
+        """One measurement.  The estimate follows a rise at once and forgets it at 10 % per measurement: a close-up
+        iteration (or an exploding scale early in training) costs its own iterations, not the rest of the run."""
+        self.demand = max(float(wanted), 0.9 * self.demand)
+
+
+def wanted_from_histogram(words):
+    """Capacity one measurement asks for: the largest count any primitive showed -- unless that is an outlier.  `words` =
+    mvp_list_demand's 256 bins of width 8 (counts clamped to 2047) + the maximum.  When the maximum is more than twice the
+    99.9th percentile (one image-filling primitive among thousands), the lists are sized for 2 x that percentile and
+    the few primitives above it stay on the ray-centric kernel, which marches only their packets: sizing N*K lists for one
+    primitive would cost gigabytes (N*K*cap*8 bytes; C2: 2.6 MB per unit of capacity)."""
+    hist, mx = words[:256], int(words[256])
+    n = sum(hist)
+    if n == 0:
+        return 0
+    allowed, acc, q = n // 1000, 0, 0       # primitives allowed above the percentile
+    for b in range(255, -1, -1):
+        acc += hist[b]
+        if acc > allowed:
+            q = 8 * b + 7                   # upper edge of the bin that holds the percentile
+            break
+    return mx if mx <= 2 * max(q, 16) else 2 * max(q, 16)
 
 
 _LIST_DEMAND = {}  # (device index, H, W, K) -> _ListDemand
+_LIST_BYTES_MIN = 64 << 20  # the lists of a call may take this much ...
+_LIST_BYTES_PER_PRIM = 2048  # ... or this much per primitive (a quarter of an 8^3 slab), whichever is more
 
 
-def primlist_capacity(H, W, K, device=None):
+def primlist_capacity(H, W, K, device=None, N=None):
     """Per-primitive capacity of the packet lists handed from forward to backward.  First call of a shape: a heuristic
     -- on head-like scenes a packet (8x8 pixels) lists ~19 primitives and ~46 % of the packets hit anything (measured, C2),
-    so a primitive is listed by ~9-10 * packets / K packets; four times that, at least 32.  Afterwards: 1.25 x the largest
-    demand any primitive of this shape has shown so far (`note_list_demand`, read one call late and without a host
-    synchronisation), so a close-up camera costs ONE iteration with some primitives on the ray-centric kernel, not all
-    of them.  Multiple of 8 (the library reads lists 32 bytes at a time), at most 2048."""
+    so a primitive is listed by ~9-10 * packets / K packets; four times that, at least 32.  Afterwards: 1.25 x the measured
+    demand (`note_list_demand`: read one call late and without a host synchronisation; outliers clipped, decaying --
+    `_ListDemand.note`, `wanted_from_histogram`), kept while the new value is within [0.6, 1] of the one in use so that
+    the allocation size does not flutter.  Multiple of 8 (the library reads lists 32 bytes at a time), at most 2048, and --
+    when N is given -- at most what a memory budget of max(64 MiB, 2 KiB per primitive) allows, never below 32: primitives
+    over the capacity are handled by the ray-centric kernel, correctly and slowly."""
     packets = ((H + 7) // 8) * ((W + 7) // 8)
-    cap = max(32.0, 4 * 10.0 * packets / max(K, 1))
+    cap = (int(min(max(32.0, 4 * 10.0 * packets / max(K, 1)), 2048)) + 7) // 8 * 8
     st = _LIST_DEMAND.get((getattr(device, "index", None), H, W, K)) if device is not None else None
     if st is not None:
         st.poll()
-        if st.hwm > 0:
-            cap = max(32.0, 1.25 * st.hwm)
-    return (int(min(cap, 2048)) + 7) // 8 * 8
+        if st.demand > 0:
+            cap = (int(min(max(32.0, 1.25 * st.demand), 2048)) + 7) // 8 * 8
+            if st.cap and 0.6 * st.cap <= cap <= st.cap:
+                cap = st.cap
+            st.cap = cap
+    if N is not None and N * K > 0:
+        budget = max(_LIST_BYTES_MIN, _LIST_BYTES_PER_PRIM * N * K)
+        cap = max(32, min(cap, budget // (8 * N * K) // 8 * 8))
+    return cap
 
 
 def note_list_demand(pl_count, N, H, W, K):
-    """Queue a read-back of max over primitives of the packets the forward counted (stream-ordered behind it, before any
-    backward marks the counters): a device reduction, a 4-byte copy into pinned memory and an event.  At most one in
-    flight per shape; nothing happens while a stream is being captured."""
+    """Queue a read-back of the demand statistics of the counters the forward has just written (stream-ordered behind it,
+    before any backward marks them): one histogram launch (mvp_list_demand), a 1 KB copy into pinned memory and an event.
+    At most one in flight per shape; nothing happens while a stream is being captured."""
     dev = pl_count.device
     if N * K == 0 or torch.cuda.is_current_stream_capturing():
         return
@@ -61,9 +96,11 @@ def note_list_demand(pl_count, N, H, W, K):
     st.poll()
     if st.event is not None:
         return
-    if st.word is None:
-        st.word = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-    st.word.copy_(pl_count[:N * K].max().reshape(1), non_blocking=True)
+    if st.words is None:
+        st.words = torch.zeros(257, dtype=torch.int32, pin_memory=True)
+        st.hist = torch.empty(257, dtype=torch.int32, device=dev)
+    _lib.check(_lib.get_lib().mvp_list_demand(ptr(pl_count), N * K, ptr(st.hist), stream_ptr(dev)), "mvp_list_demand")
+    st.words.copy_(st.hist, non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record(torch.cuda.current_stream(dev))
 
@@ -72,7 +109,7 @@ def alloc_handoff(N, H, W, K, dev):
     """Hand-off buffers of the primitive-centric backward (include/mvp_abi.h): per-ray saturation record, per-primitive
     counters + flags + per-packet words (zeroed by the library), and per primitive the list of ray packets that touch it.
     Returns (rayaux, pl_count, pl_list, pl_cap)."""
-    pl_cap = primlist_capacity(H, W, K, dev)
+    pl_cap = primlist_capacity(H, W, K, dev, N)
     rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
     pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
     pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)

@@ -31,40 +31,91 @@ from ._tensors import aligned, ptr, require_device_f32, stream_ptr
 
 _op = importlib.import_module(__package__ + ".mvpraymarch")  # (the package re-exports a function of that name)
 
-# rayrgba.data_ptr() -> ((N, H, W, K), rayaux, pl_count, pl_list, pl_cap).  An entry lives exactly as long as the
-# rayrgba STORAGE: a finaliser on the storage object removes it (a forward whose backward never runs leaks nothing, and
-# the caching allocator cannot hand the address to another tensor while the entry exists).
+# rayrgba.data_ptr() -> ((N, H, W, K), rayaux, pl_count, pl_list, pl_cap), in order of insertion.  An entry lives at most as
+# long as the rayrgba STORAGE (a finaliser on the storage object removes it: a forward whose backward never runs leaks
+# nothing, and the caching allocator cannot hand the address to another tensor while the entry exists) -- and the dict is
+# bounded in BYTES: a caller that keeps grad-mode images alive (logging, evaluation without no_grad) would otherwise keep
+# every forward's hand-off buffers with them.  Over the budget the oldest entries go; a backward that finds none takes the
+# ray-centric kernel, which needs no hand-off (correct, slow).
 _HANDOFF = {}
+HANDOFF_BYTES_MAX = 4 << 30
+
+
+def _entry_bytes(ent):
+    return sum(t.numel() * t.element_size() for t in ent[1:4] if t is not None)
 
 
 def _handoff_put(rayrgba, shape, buffers):
     key = rayrgba.data_ptr()
+    _HANDOFF.pop(key, None)
     _HANDOFF[key] = (shape,) + tuple(buffers)
     weakref.finalize(rayrgba.untyped_storage(), _HANDOFF.pop, key, None)
+    total = sum(_entry_bytes(e) for e in _HANDOFF.values())
+    for k in list(_HANDOFF):          # oldest first; the entry just added stays
+        if total <= HANDOFF_BYTES_MAX or k == key:
+            break
+        total -= _entry_bytes(_HANDOFF.pop(k))
 
 
 def _handoff_take(rayrgba, shape):
     """The buffers of the grad-mode forward that wrote `rayrgba`, or Nones (-> ray-centric backward) when there was
-    none or its geometry is not this call's.  Left in place: a second backward over the same forward (retain_graph)
-    finds them again; the storage's finaliser removes them."""
+    none (or it was evicted) or its geometry is not this call's.  Left in place: a second backward over the same forward
+    (retain_graph) finds them again; the storage's finaliser removes them."""
     ent = _HANDOFF.get(rayrgba.data_ptr())
     if ent is None or ent[0] != shape:
         return None, None, None, 0
     return ent[1:]
 
 
+STRICT_ORDER_CHECK = False  # True: validate `sortedobjid` with a host synchronisation inside the call (debugging)
+_ORDER_PENDING = []   # [(event, pinned word)]: device-side checks of earlier calls not yet looked at
+_ARANGE = {}          # (device index, K, dtype) -> arange(K)
+
+
+def _poll_order_checks(wait=False):
+    """Look at the checks of earlier calls that have completed (all of them with wait=True); raise for a bad order."""
+    keep = []
+    for ev, word in _ORDER_PENDING:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            if int(word[0]) != 0:
+                _ORDER_PENDING[:] = []
+                raise NotImplementedError(
+                    "sortedobjid of an EARLIER raymarch call was not the fixed identity order (its results are in the "
+                    "wrong composition order): only usebvh='fixedorder' without randomorder is supported")
+        else:
+            keep.append((ev, word))
+    _ORDER_PENDING[:] = keep
+
+
 def _identity_order(sortedobjid, K):
     """usebvh='fixedorder' hands arange(K) per image (mvpraymarch.py:45); any other order (randomorder=True, the LBVH
-    path) would silently render in the wrong composition order here."""
+    path) would silently render in the wrong composition order here.  The reference's glue builds a NEW sortedobjid on
+    every forward, so this runs on every call of the drop-in path and must not block the host: shape errors raise at once,
+    the CONTENT is compared on the device, the one-word verdict travels to pinned memory behind an event and is looked at by
+    the next calls (the error is then raised one call late; `STRICT_ORDER_CHECK = True` waits for it inside the call).
+    Nothing is enqueued while a stream is being captured."""
     if sortedobjid is None:
         return
-    hit = getattr(sortedobjid, "_mvp_identity", None)
-    if hit != sortedobjid._version:
-        ar = torch.arange(K, device=sortedobjid.device, dtype=sortedobjid.dtype)
-        if sortedobjid.dim() != 2 or sortedobjid.size(1) != K or not bool((sortedobjid == ar[None]).all()):
-            raise NotImplementedError("sortedobjid is not the fixed identity order: only usebvh='fixedorder' without "
-                                      "randomorder is supported")
-        sortedobjid._mvp_identity = sortedobjid._version
+    _poll_order_checks()
+    if sortedobjid.dim() != 2 or sortedobjid.size(1) != K:
+        raise NotImplementedError("sortedobjid must be [N, K] in the fixed identity order (usebvh='fixedorder')")
+    if getattr(sortedobjid, "_mvp_identity", None) == sortedobjid._version or torch.cuda.is_current_stream_capturing():
+        return
+    dev = sortedobjid.device
+    key = (dev.index, K, sortedobjid.dtype)
+    ar = _ARANGE.get(key)
+    if ar is None:
+        ar = _ARANGE[key] = torch.arange(K, device=dev, dtype=sortedobjid.dtype)
+    word = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    word.copy_((sortedobjid != ar[None]).any().to(torch.int32).reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _ORDER_PENDING.append((ev, word))
+    sortedobjid._mvp_identity = sortedobjid._version
+    if STRICT_ORDER_CHECK or len(_ORDER_PENDING) > 64:
+        _poll_order_checks(wait=True)
 
 
 def compute_morton(*args):

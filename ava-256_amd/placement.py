@@ -62,24 +62,21 @@ def _as_int32(idxim):
     return hit[1]
 
 
-_CHECKED = {}  # (data_ptr, _version, numel, V) of index tensors already validated (bounded: cleared at 64 entries)
-
-
 def _check_indices(idxim, V):
     """The kernels index geo with idxim directly; the reference's index_select raises on an index outside [0, V)
-    (assembler.py:118-122), so this does too -- once per index tensor, version and V: two device reductions and a host
-    synchronisation the FIRST time only (the index map is a registered buffer: one tensor for the life of the module).
-    Keyed by address + version + size, so a `.to()` / clone of the same data is checked once more and no more; skipped
-    while a stream is being captured (nothing here can be captured; a captured graph replays validated tensors)."""
-    key = (idxim.data_ptr(), idxim._version, idxim.numel(), int(V))
-    if key in _CHECKED or torch.cuda.is_current_stream_capturing():
+    (assembler.py:118-122), so this does too -- once per index tensor OBJECT, version and V: two device reductions and a
+    host synchronisation the first time only (the index map is a registered buffer: one tensor for the life of the
+    module).  The mark rides on the tensor object, like the int32 copy: an address-keyed cache would be fooled by the
+    caching allocator, which hands a freed address to the next tensor of the same size with _version 0 -- and an
+    unvalidated index is an out-of-bounds device access.  A fresh tensor per call is validated per call.  Skipped while a
+    stream is being captured (nothing here can be captured; a captured graph replays validated tensors)."""
+    key = (idxim._version, int(V))
+    if getattr(idxim, "_mvp_checked", None) == key or torch.cuda.is_current_stream_capturing():
         return
     lo, hi = int(idxim.min().item()), int(idxim.max().item())
     if lo < 0 or hi >= V:
         raise IndexError("idxim holds vertex indices in [%d, %d] but geo has %d vertices" % (lo, hi, V))
-    if len(_CHECKED) >= 64:
-        _CHECKED.clear()
-    _CHECKED[key] = True
+    idxim._mvp_checked = key
 
 
 def prim_placement(geo, idxim, barim, volradius, nprims):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 10
+#define MVP_ABI_VERSION 11
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -131,6 +131,12 @@ int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const fl
                        const float *grad_rayrgba, float *grad_primpos, float *grad_primrot, float *grad_primscale,
                        float *grad_tplate, float *grad_warp /*NULL iff warp is NULL*/, float fadescale,
                        float fadeexp, uint32_t *diag, void *stream);
+
+/* Demand statistics of the forward -> backward packet lists (no counterpart in the reference: its backward re-marches
+ * every ray, mvpraymarch_subset_kernel.h:102-216).  `primlist_count` [nprims] as the grad-mode forward left it (the
+ * counters keep counting past primlist_cap).  Writes hist[0..255] = number of primitives whose count, clamped to 2047,
+ * lies in [8 b, 8 b + 8), hist[256] = the largest count.  `hist` (257 words) is zeroed by the call. */
+int mvp_list_demand(const uint32_t *primlist_count, long long nprims, uint32_t *hist /*[257]*/, void *stream);
 
 /* Which thread block of the march grids does what -- a host-side evaluation of the same functions the kernels use
  * (tests and tools; no device work).  The grids are XCD-aware: block b runs on XCD b % 8, whole images go to single XCDs

@@ -144,13 +144,16 @@ int mvpo_aabb(int N, int K, const real *pos, const real *rot, const real *scale,
 
 /* utils.h:679-685 */
 static int ray_aabb_hit_ird(const real *p0, const real *p1, const real *o, const real *ird) {
-    real tn = -INFINITY, tf = INFINITY;
+    /* max_component / min_component are fmaxf(fmaxf(x,y),z) / fminf(fminf(x,y),z) (utils.h:659-665): a NaN axis is
+     * ignored, but three NaN axes give NaN and the comparison fails -- a box with NaN corners is never entered.
+     * (Folding from -inf / +inf instead would answer "hit" there.) */
+    real lo[3], hi[3];
     for (int j = 0; j < 3; ++j) {
         real t0 = (p0[j] - o[j]) * ird[j], t1 = (p1[j] - o[j]) * ird[j];
-        tn = rmax(tn, rmin(t0, t1));
-        tf = rmin(tf, rmax(t0, t1));
+        lo[j] = rmin(t0, t1);
+        hi[j] = rmax(t0, t1);
     }
-    return tn <= tf;
+    return rmax(rmax(lo[0], lo[1]), lo[2]) <= rmin(rmin(hi[0], hi[1]), hi[2]);
 }
 
 typedef struct {
@@ -180,15 +183,17 @@ static int traverse(int K, const real *o, const real *d, const real *A, const re
             int k = node - (K - 1);
             const real *p = pos + (size_t)k * 3, *R = rot + (size_t)k * 9, *s = scale + (size_t)k * 3;
             real xmt[3] = {o[0] - p[0], o[1] - p[1], o[2] - p[2]};
-            real tn = -INFINITY, tf = INFINITY;
+            real lo[3], hi[3];
             for (int j = 0; j < 3; ++j) { /* primtransf.h:134-153 + utils.h:747-753 */
                 real r0 = (R[0 + j] * xmt[0] + R[3 + j] * xmt[1] + R[6 + j] * xmt[2]) * s[j];
                 real rd = (R[0 + j] * d[0] + R[3 + j] * d[1] + R[6 + j] * d[2]) * s[j];
                 real irdj = (real)1 / rd;
                 real t0 = ((real)-1 - r0) * irdj, t1 = ((real)1 - r0) * irdj;
-                tn = rmax(tn, rmin(t0, t1));
-                tf = rmin(tf, rmax(t0, t1));
+                lo[j] = rmin(t0, t1);
+                hi[j] = rmax(t0, t1);
             }
+            /* utils.h:752-755 with max_component / min_component (utils.h:659-665): all-NaN -> NaN -> no hit */
+            const real tn = rmax(rmax(lo[0], lo[1]), lo[2]), tf = rmin(rmin(hi[0], hi[1]), hi[2]);
             if (tn <= tf) {
                 *rtmin = rmin(*rtmin, tn);
                 *rtmax = rmax(*rtmax, tf);

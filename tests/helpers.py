@@ -96,3 +96,84 @@ def make_placement_inputs(nprims, B=None, V=7306, T=1024, seed=77):
     w = (rng.normal(size=(B, nprims, 3)).astype(np.float32), rng.normal(size=(B, ny, nx, 3)).astype(np.float32),
          rng.normal(size=(B, ny, nx, 3)).astype(np.float32))
     return geo, idxim, barim, 256.0, w
+
+
+# ---- degenerate / non-finite primitive inputs (tests/test_gpu_hardening.py, tests/test_oracle_degenerate.py) -------------
+DEGENERATE_CASES = ["scale0_some", "scale0_all", "scale0_axis_aligned", "scale_inf_some", "nan_alpha_slab", "nan_rgb_voxel",
+                    "inf_alpha_voxel", "nan_primpos", "inf_primpos", "nan_primrot", "tmin_eq_tmax"]
+
+
+def degenerate_case(name, oracle):
+    """Inputs of one degenerate-input scene (numpy, float32 values), as the reference's callers can produce them:
+
+      scale0_*        a fresh DecoderAssembler has adaptwarps = 0 (models/decoders/assembler.py:66,199) => primscale = 0 =>
+                      1/scale = inf in the AABB corners (primtransf.h:12-63) unless running_avg_scale ran first
+                      (ddp-train.py:374-377).  With a general rotation the leaf box becomes (-inf, +inf)^3, every ray
+                      "hits" the primitive (r0 = rd = 0 -> slab interval (-inf, +inf), utils.h:744-755) and samples its
+                      centre voxel cell at EVERY lattice step of the ray; with an axis-aligned rotation the corners are
+                      inf * 0 = NaN, the box is NaN and the reference never enters it (utils.h:659-665,679-685);
+      scale_inf_some  box-space coordinates are +-inf / NaN: never hit;
+      nan_* / inf_*   what a diverged decoder hands over (ddp-train.py:436-439,469-472 exist because it happens): NaN / Inf in
+                      the slab of ONE visible primitive, in one primitive's position / rotation;
+      tmin_eq_tmax    rays whose march interval is a single point: one lattice step at most (subset_kernel.h:66-72,84).
+    Returns a dict of arrays + stepsize; `poisoned` lists the primitives touched."""
+    from ava256_amd.scene import make_scene
+    N, H, W, K = (1, 24, 24, 16) if name == "scale0_all" else (1, 40, 40, 64)
+    s = make_scene(N, H, W, K, device="cpu", seed=5, alpha_gain=1.0)
+    rp, rd, tm = scene_rays(oracle, s)
+    a = {k: s[k].numpy().copy() for k in ("primpos", "primrot", "primscale", "template")}
+    vis = [9, 27, 36]   # primitives the front cameras see (asserted by the tests through the clean gradient)
+    one = vis[1]
+    poisoned = []
+    if name == "scale0_some":
+        a["primscale"][0, vis] = 0.0
+        poisoned = vis
+    elif name == "scale0_all":
+        a["primscale"][:] = 0.0
+        poisoned = list(range(K))
+    elif name == "scale0_axis_aligned":
+        a["primscale"][0, vis] = 0.0
+        a["primrot"][0, vis] = np.eye(3, dtype=np.float32)
+        poisoned = vis
+    elif name == "scale_inf_some":
+        a["primscale"][0, vis] = np.inf
+        poisoned = vis
+    elif name == "nan_alpha_slab":
+        a["template"][0, one, ..., 3] = np.nan
+        poisoned = [one]
+    elif name == "nan_rgb_voxel":
+        a["template"][0, one, 3:5, 3:5, 3:5, 1] = np.nan
+        poisoned = [one]
+    elif name == "inf_alpha_voxel":
+        a["template"][0, one, 3:5, 3:5, 3:5, 3] = np.inf
+        poisoned = [one]
+    elif name == "nan_primpos":
+        a["primpos"][0, one, 1] = np.nan
+        poisoned = [one]
+    elif name == "inf_primpos":
+        a["primpos"][0, one, 1] = np.inf
+        poisoned = [one]
+    elif name == "nan_primrot":
+        a["primrot"][0, one, 1, 2] = np.nan
+        poisoned = [one]
+    elif name == "tmin_eq_tmax":
+        t0 = tm[..., 0] + 0.5 * (tm[..., 1] - tm[..., 0])   # a point in the middle of the volume: inside the shell for most rays
+        tm = np.stack([t0, t0], -1)
+    else:
+        raise KeyError(name)
+    return dict(raypos=rp, raydir=rd, tminmax=tm, stepsize=s["stepsize"], poisoned=poisoned, visible=vis, **a)
+
+
+def assert_same_poison(got, ref, tol, what):
+    """`got` (kernel) against `ref` (float64 oracle) where the reference's arithmetic yields non-finite values: the SAME
+    elements are non-finite (NaN where NaN, +-inf where +-inf), every other element within tol * max |finite ref|."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    nan_r, nan_g = np.isnan(ref), np.isnan(got)
+    assert (nan_r == nan_g).all(), (what, "NaN pattern differs", int(nan_r.sum()), int(nan_g.sum()), int((nan_r != nan_g).sum()))
+    inf_r, inf_g = np.isinf(ref), np.isinf(got)
+    assert (inf_r == inf_g).all() and (np.sign(ref[inf_r]) == np.sign(got[inf_g])).all(), (what, "Inf pattern differs")
+    fin = np.isfinite(ref)
+    if fin.any():
+        scale = max(np.abs(ref[fin]).max(), 1e-30)
+        err = np.abs(got[fin] - ref[fin]).max()
+        assert err <= tol * scale, (what, err, scale)

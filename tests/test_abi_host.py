@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 11
     assert b"bad argument" in lib.mvp_error_string(-1)
     assert lib.mvp_error_string(0) == b"ok"
 
@@ -147,8 +147,10 @@ def test_no_cpu_fallback():
 
 def test_list_capacity_policy_on_the_host():
     """Host logic of the forward->backward list capacity (ava-256_amd/mvpraymarch.py): the first call of a shape uses the
-    heuristic, later calls 1.25 x the high-water mark of the measured demand, always a multiple of 8 (the library reads
-    lists 32 bytes at a time and rejects capacities that are not a multiple of 4), at least 32, at most 2048."""
+    heuristic, later calls 1.25 x the measured demand, always a multiple of 8 (the library reads lists 32 bytes at a time
+    and rejects capacities that are not a multiple of 4), at least 32, at most 2048.  The demand is robust: one outlier
+    primitive does not size everybody's list, a spike decays, the capacity does not flutter, and N*K*cap*8 bytes stay
+    inside a budget."""
     import importlib
     op = importlib.import_module("ava256_amd.mvpraymarch")
     dev = torch.device("cuda", 0)   # only its index is used as a key
@@ -158,10 +160,43 @@ def test_list_capacity_policy_on_the_host():
     assert cap0 == 40 and cap0 % 8 == 0                        # 4 x 10 x 4096 packets / 4096 primitives
     assert op.primlist_capacity(64, 64, 16384, dev) == 32      # never below 32
     assert op.primlist_capacity(4096, 4096, 16, dev) == 2048   # never above 2048
-    st = op._LIST_DEMAND.setdefault(key, op._ListDemand())
-    for hwm, want in ((10, 32), (61, 80), (100, 128), (5000, 2048)):
-        st.hwm = hwm
+    for demand, want in ((10, 32), (61, 80), (100, 128), (5000, 2048)):
+        st = op._LIST_DEMAND[key] = op._ListDemand()
+        st.note(demand)
         cap = op.primlist_capacity(512, 512, 4096, dev)
-        assert cap == want and cap % 8 == 0 and cap >= min(hwm, 2048), (hwm, cap)
+        assert cap == want and cap % 8 == 0 and cap >= min(demand, 2048), (demand, cap)
     op._LIST_DEMAND.pop(key, None)
     assert op.primlist_capacity(512, 512, 4096, None) == cap0  # no device: the heuristic
+
+    def hist_of(counts):
+        h = [0] * 257
+        for c in counts:
+            h[min(c, 2047) >> 3] += 1
+        h[256] = max(counts)
+        return h
+
+    # the whole distribution moved (close-up camera): the maximum is what is wanted
+    assert op.wanted_from_histogram(hist_of([60] * 3000 + [90] * 1000 + [101])) == 101
+    # ONE image-filling primitive among 4096 (the advisor's case): sized for 2 x the 99.9th percentile, not for it
+    w = op.wanted_from_histogram(hist_of([12] * 4000 + [20] * 95 + [1900]))
+    assert 32 <= w <= 64, w
+    assert op.wanted_from_histogram([0] * 257) == 0
+    # a spike is followed at once and forgotten at 10 % per measurement; the capacity in use moves only out of [0.6, 1] x
+    st = op._LIST_DEMAND[key] = op._ListDemand()
+    st.note(20)
+    c_norm = op.primlist_capacity(512, 512, 4096, dev)
+    st.note(1500)
+    c_spike = op.primlist_capacity(512, 512, 4096, dev)
+    assert c_norm == 32 and c_spike == 1880
+    seen = []
+    for _ in range(60):
+        st.note(20)
+        seen.append(op.primlist_capacity(512, 512, 4096, dev))
+    assert seen[0] == c_spike and seen[-1] <= 48 and sorted(seen, reverse=True) == seen
+    assert len(set(seen)) <= 12, sorted(set(seen))              # steps, not a new allocation size per call
+    # memory budget: at C2 (80 x 4096 primitives) the lists never pass max(64 MiB, 2 KiB per primitive) = 640 MiB
+    st.note(1500)
+    capb = op.primlist_capacity(512, 512, 4096, dev, N=80)
+    assert capb == 256 and 80 * 4096 * capb * 8 <= 2048 * 80 * 4096
+    assert op.primlist_capacity(512, 512, 4096, dev, N=1) == 1880   # one image: 64 MiB allow it
+    op._LIST_DEMAND.pop(key, None)

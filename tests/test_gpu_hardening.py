@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import ROOT
-from helpers import FragileRays, cosine, npf, scene_rays, to_dev
+from helpers import (DEGENERATE_CASES, FragileRays, assert_same_poison, cosine, degenerate_case, npf, scene_rays, to_dev)
 from test_gpu_parity import BACKWARD_MODES, FWD_TOL, _check_grads, _march, ops  # noqa: F401  (ops is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -347,3 +347,47 @@ def test_list_capacity_follows_the_demand(ops, oracle64):
     assert flags1 & 1, "the scene is meant to overflow the heuristic capacity on the first call"
     assert cap1 > cap0 and cap2 == cap1
     assert flags2 & 7 == 0, flags2          # second call: nothing left the primitive-centric path
+
+
+@pytest.mark.parametrize("mode", BACKWARD_MODES)
+@pytest.mark.parametrize("case", DEGENERATE_CASES)
+def test_degenerate_primitive_inputs(ops, oracle64, case, mode):
+    """Degenerate and non-finite PRIMITIVE inputs (tests/helpers.py: degenerate_case; the reference semantics of every case
+    are pinned on CPU in tests/test_oracle_degenerate.py): primscale = 0 (a fresh DecoderAssembler: adaptwarps = 0,
+    models/decoders/assembler.py:66,199 -> 1/scale = inf in primtransf.h:12-63), primscale = inf, NaN / Inf in the slab, the
+    position or the rotation of ONE primitive (a diverged decoder, ddp-train.py:436-439), rays with tmin = tmax.  The kernels
+    must poison exactly the elements the reference's arithmetic poisons (same NaN / Inf pattern in the image and in every
+    gradient), be within the standing tolerances everywhere else, in all three backward ownership modes -- and come back
+    in bounded time (an all-infinite AABB tree, 500-step crossings)."""
+    import time
+    c = degenerate_case(case, oracle64)
+    a = (c["raypos"], c["raydir"], c["stepsize"], c["tminmax"], c["primpos"], c["primrot"], c["primscale"], c["template"])
+    with np.errstate(all="ignore"):
+        ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
+    rng = np.random.default_rng(3)
+    gout = rng.normal(size=ref_rgba.shape)
+    SENT = 12345.0   # NaN-aware comparison of raysat: a NaN on one side only must count as a difference
+    margin = np.where(np.isfinite(st["margin"]), st["margin"], 0.0)
+    fragile = FragileRays(np.nan_to_num(ref_sat, nan=SENT, posinf=SENT, neginf=-SENT), margin, gout, max_frac=0.01, min_allowed=4)
+    t0 = time.time()
+    rgba, grads, diag = _march(ops, *a, 8.0, 8.0, mode=mode,
+                               grad_out=lambda hs: fragile(np.nan_to_num(hs, nan=SENT, posinf=SENT, neginf=-SENT)))
+    elapsed = time.time() - t0
+    assert elapsed < 60.0, elapsed
+    with np.errstate(all="ignore"):
+        gp, gr, gs, gt = oracle64.march_backward(*a, ref_sat, fragile.masked())
+    fr = fragile.mask
+    assert_same_poison(rgba[~fr], ref_rgba[~fr], 4 * FWD_TOL, case + " rgba")
+    nbad = {k: int((~np.isfinite(v)).sum()) for k, v in (("template", gt), ("primpos", gp), ("primrot", gr), ("primscale", gs))}
+    print("%s (%s): %.2f s, %d fragile rays, oracle non-finite elements %s, flags %#x" % (
+        case, mode, elapsed, int(fr.sum()), nbad, diag.get("handoff_flags", -1)))
+    assert_same_poison(grads["template"], gt, GT_TOL_DEGENERATE, case + " grad_template")
+    for k, ref in (("primpos", gp), ("primrot", gr), ("primscale", gs)):
+        assert_same_poison(grads[k], ref, POSE_TOL_DEGENERATE, case + " grad_" + k)
+        fin = np.isfinite(ref) & np.isfinite(grads[k])
+        if np.abs(ref[fin]).max() > 0:
+            assert cosine(grads[k][fin], ref[fin]) >= 0.9999, (case, k)
+
+
+GT_TOL_DEGENERATE = 1e-3     # grad_template: the standing 1e-3 of max |g| (finite elements)
+POSE_TOL_DEGENERATE = 3e-2   # pose gradients: the standing white-noise bound

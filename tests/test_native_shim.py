@@ -108,3 +108,78 @@ def test_reference_call_sequence_through_the_shims():
     assert torch.equal(grad_template, t["template"].grad)      # primitive-centric path taken by the shim as well
     for mine, k in ((grad_primpos, "primpos"), (grad_primrot, "primrot"), (grad_primscale, "primscale")):
         assert (mine - t[k].grad).abs().max().item() <= 1e-4 * t[k].grad.abs().max().item(), k
+
+
+def test_handoff_buffers_are_bounded_in_bytes():
+    """native_shim keeps the forward's hand-off buffers keyed by the rayrgba storage; a caller that keeps grad-mode images
+    alive must not keep every forward's buffers with them: over HANDOFF_BYTES_MAX the oldest entries go (their backward
+    then takes the ray-centric kernel), the newest always stays, and a dying storage removes its own entry."""
+    from ava256_amd import native_shim as ns
+    old_max, old = ns.HANDOFF_BYTES_MAX, dict(ns._HANDOFF)
+    ns._HANDOFF.clear()
+    try:
+        ns.HANDOFF_BYTES_MAX = 3000
+        imgs = [torch.zeros(4, 4) for _ in range(5)]
+        bufs = lambda: (torch.zeros(100), torch.zeros(50), torch.zeros(100), 8)     # 1000 bytes
+        for im in imgs:
+            ns._handoff_put(im, (1, 2, 2, 3), bufs())
+        assert len(ns._HANDOFF) == 3                                   # 5000 bytes offered, 3000 kept: the oldest two went
+        assert ns._handoff_take(imgs[0], (1, 2, 2, 3))[0] is None      # evicted -> ray-centric backward
+        assert ns._handoff_take(imgs[4], (1, 2, 2, 3))[3] == 8         # the newest is there
+        assert ns._handoff_take(imgs[4], (1, 2, 2, 4))[0] is None      # other geometry: not this forward's
+        ns._handoff_put(imgs[0], (1, 2, 2, 3), (torch.zeros(5000), None, None, 8))   # one entry over the budget: it stays
+        assert list(ns._HANDOFF) == [imgs[0].data_ptr()]
+        k = imgs[0].data_ptr()
+        del imgs
+        import gc
+        gc.collect()
+        assert k not in ns._HANDOFF                                    # the storage's finaliser
+    finally:
+        ns.HANDOFF_BYTES_MAX = old_max
+        ns._HANDOFF.clear()
+        ns._HANDOFF.update(old)
+
+
+@pytest.mark.gpu
+def test_shim_order_check_without_a_host_synchronisation():
+    """raymarch_forward's sortedobjid must be the fixed identity order (mvpraymarch.py:45).  The reference's glue builds a
+    new tensor per forward, so the check runs per call and must not block: the verdict is computed on the device and read
+    by a LATER call.  Identity passes (every call); a permuted order raises -- at the next call, or inside the call with
+    STRICT_ORDER_CHECK; a wrong shape raises at once."""
+    import extensions.mvpraymarch.mvpraymarchlib as lib
+    from ava256_amd import native_shim as ns
+    from ava256_amd.scene import make_scene
+    N, H, W, K = 1, 32, 32, 64
+    s = make_scene(N, H, W, K, device="cuda", seed=5)
+    import ava256_amd as ops
+    rp, rd, tm = ops.compute_raydirs(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"], s["volradius"])
+    dev = rp.device
+    nodechildren = torch.zeros((N, 2 * K - 1, 2), dtype=torch.int32, device=dev)
+    nodeaabb = torch.empty((N, 2 * K - 1, 2, 3), device=dev)
+    lib.compute_aabb(s["primpos"], s["primrot"], s["primscale"], None, nodechildren, None, nodeaabb, 0)
+
+    def fwd(order):
+        rgba = torch.empty((N, H, W, 4), device=dev)
+        lib.raymarch_forward(rp, rd, s["stepsize"], tm, order, nodechildren, nodeaabb, s["primpos"], s["primrot"],
+                             s["primscale"], s["template"], None, rgba, None, None, 0, False, 512, True, True)
+        return rgba
+
+    ns._poll_order_checks(wait=True)
+    ident = lambda: (torch.arange(N * K, dtype=torch.int32, device=dev) % K).view(N, K)
+    for _ in range(3):
+        fwd(ident())                                   # a fresh tensor per call, like the reference's build_accel
+    ns._poll_order_checks(wait=True)                   # nothing to report
+    perm = ident().flip(1).contiguous()
+    fwd(perm)                                          # enqueued, not yet judged
+    torch.cuda.synchronize()
+    with pytest.raises(NotImplementedError):
+        fwd(ident())                                   # ... the next call reports it
+    ns._poll_order_checks(wait=True)                   # (and the report is not repeated)
+    ns.STRICT_ORDER_CHECK = True
+    try:
+        with pytest.raises(NotImplementedError):
+            fwd(ident().flip(1).contiguous())
+    finally:
+        ns.STRICT_ORDER_CHECK = False
+    with pytest.raises(NotImplementedError):
+        fwd(ident()[:, : K // 2].contiguous())
