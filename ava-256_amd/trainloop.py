@@ -378,6 +378,14 @@ class Trainer:
         self._clipper = None
         self.last_grad_norm = None
 
+    @classmethod
+    def from_config(cls, model, cfg, **kw):
+        """`cfg` = config.load_train_config(<the reference's YAML>): its learning rate, schedule, clip and loss weights
+        (configs/config.yaml:9-21; ddp-train.py:78,82,404-430,441)."""
+        args = dict(cfg["trainer"])
+        args.update(kw)
+        return cls(model, **args)
+
     def losses(self, output, batch):
         """ddp-train.py:404-418.  A term whose inputs the model does not produce (no geometry branch, no VAE pair) is
         skipped, like a key absent from the reference's `loss_weights`."""

@@ -67,15 +67,16 @@ def algorithmic_bytes(N, H, W, K, V=512):
     return fwd, bwd
 
 
-def cpu_baseline(N, H, W, K, slab, budget_s=20.0):
-    """Time the fp32 CPU port (oracle/, OpenMP over rays) on a bounded sample of the same workload."""
+def cpu_baseline(N, H, W, K, slab, budget_s=20.0, cams=1):
+    """Time the fp32 CPU port (oracle/, OpenMP over rays) on a bounded sample of the same workload (`cams` cameras of it per
+    pass)."""
     import numpy as np
     from ava256_amd.scene import make_scene
     from oracle.mvp_oracle import Oracle
 
     cores = os.cpu_count() or 1
     o = Oracle("f32")
-    s = make_scene(1, H, W, K, device="cpu", seed=1112, slab=slab)
+    s = make_scene(cams, H, W, K, device="cpu", seed=1112, slab=slab)
     npv = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in s.items()}
 
     def one_pass():
@@ -92,10 +93,10 @@ def cpu_baseline(N, H, W, K, slab, budget_s=20.0):
     tt = t1
     for _ in range(reps - 1):
         tt += one_pass()
-    rays = reps * H * W
+    rays = reps * cams * H * W
     return {"value": rays / tt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d x (1 camera %dx%d, K=%d: raydirs+aabb+fwd+bwd) in %.1f s, OpenMP over rays, fp32" % (
-                reps, H, W, K, tt)}
+            "sample": "%d x (%d camera(s) %dx%d, K=%d: raydirs+aabb+fwd+bwd) in %.1f s, OpenMP over rays, fp32" % (
+                reps, cams, H, W, K, tt)}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -208,8 +209,19 @@ def make_march_step_gpu(args, rank, world, dev):
                                                 volradius, stepsize, (s["primpos"], s["primrot"], s["primscale"]),
                                                 s["template"])
 
+    def hit_packets():  # 8x8 ray packets with a non-empty hit list (kernel diagnostics of one untimed forward)
+        from ava256_amd import _hooks
+        diag = torch.zeros(8, dtype=torch.int32, device=dev)
+        _hooks.set_diag_buffer(diag)
+        try:
+            render()
+            torch.cuda.synchronize(dev)
+            return int(_hooks.read_diag()["packets_hit"])
+        finally:
+            _hooks.set_diag_buffer(None)
+
     return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render,
-                  "fused_step": fused_step}
+                  "fused_step": fused_step, "hit_packets_fn": hit_packets}
 
 
 def kernel_averages(events):
@@ -219,12 +231,15 @@ def kernel_averages(events):
     return {k: sum(v) / len(v) for k, v in kt.items()}
 
 
-def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None):
-    """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object."""
+def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None, config=None):
+    """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object.  `config` =
+    config.load_train_config(...) of one of the reference's YAML files: its batch size per GPU and hyper-parameters."""
     from ava256_amd import _hooks as mm
     from ava256_amd.trainloop import (BackgroundMLPStandIn, CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel,
                                       SlabDecoderStandIn, Trainer, make_training_batch)
     N, H, W, K, slab = WORKLOADS[workload]
+    if config is not None:
+        N = config["batchsize"]                     # train.batchsize: frames per GPU (ddp-train.py:321)
     ncams, nident = 80, 4
     batch, volradius = make_training_batch(N, H, W, K, dev, seed=1112 + rank, ncams=ncams, nident=nident,
                                            target_decoder=SlabDecoderStandIn(K, slab, seed=9))
@@ -233,7 +248,10 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
                                encoder=CodeEncoderStandIn()).to(dev)
     nparams = sum(p.numel() for p in model.parameters())
     ddp = (world > 1) if ddp is None else ddp
-    tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None)
+    if config is not None:
+        tr = Trainer.from_config(model, config, ddp=ddp, device_ids=[local_rank] if ddp else None)
+    else:
+        tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None)
     state = {}
 
     def step():
@@ -250,6 +268,8 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
            "ms_per_iter": 1e3 * elapsed / steps, "steps": steps, "frames_per_s": N * world * steps / elapsed,
            "allreduce_mb": nparams * 4e-6 if ddp else 0.0, "param_mb": nparams * 4e-6,
            "kernel_ms": kernel_averages(events), "final_loss": float(state["loss"]),
+           "hyper_parameters": {"lr": tr.optim.param_groups[0]["initial_lr"], "clip": tr.clip,
+                                "loss_weights": tr.loss_weights, "from": "config file" if config else "configs/config.yaml values"},
            "background_mlp": ("fused MFMA kernels (csrc/bgmlp.hip: bf16 operands, fp32 accumulation), %.1f GFLOP fwd per "
                               "iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
            if with_bg else "off (matting over a constant background)"}
@@ -258,26 +278,82 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
     return out
 
 
-def _spawned_rank(rank, world, port, argv, backend, make_step, device):
-    """Entry point of one self-launched rank (see self_launch): the environment torch.distributed.run would have set."""
+def _spawned_rank(rank, world, port, argv, backend, make_step, device, errdir):
+    """Entry point of one self-launched rank (see self_launch): the environment torch.distributed.run would have set.
+    stderr (file descriptor 2, so that RCCL's own messages are included) goes to a per-rank file the parent reads."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
-    main(argv, backend=backend, make_step=make_step, device=device)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")               # a failed rendezvous / transport says why
+    if errdir:
+        fd = os.open(os.path.join(errdir, "rank%d.err" % rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        sys.stderr.flush()
+        os.dup2(fd, 2)
+        os.close(fd)
+    try:
+        main(argv, backend=backend, make_step=make_step, device=device)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        raise
 
 
-def self_launch(argv, world, backend, make_step, device):
+def self_launch(argv, world, backend, make_step, device, timeout_s=1800.0):
     """`python bench.py --gpus N` without a launcher: spawn one process per GPU on this node (rendezvous on 127.0.0.1,
     a free port), like the reference's own `mp.spawn(run, nprocs=world_size)` (ddp-train.py:612-625).  Every rank then
     runs main() exactly as under `python -m torch.distributed.run`; rank 0 prints the one JSON line to the inherited
-    stdout.  `make_step` (tests) must be a module-level function: the ranks are started with the spawn method."""
+    stdout.  `make_step` (tests) must be a module-level function: the ranks are started with the spawn method.
+
+    A rank that dies, raises or hangs must not leave the caller with a bare traceback (or nothing): the ranks are polled,
+    killed at `timeout_s`, and on any failure ONE JSON line carrying "error", the failing rank and the tail of its stderr
+    (NCCL_DEBUG=WARN output included) is printed in the bench's own format; the exit status is then 1."""
+    import shutil
     import socket
+    import tempfile
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     sys.stdout.flush()
-    mp.spawn(_spawned_rank, args=(world, port, argv, backend, make_step, device), nprocs=world, join=True)
+    errdir = tempfile.mkdtemp(prefix="bench_ranks_")
+    failure = None
+    t0 = time.monotonic()
+    ctx = mp.spawn(_spawned_rank, args=(world, port, argv, backend, make_step, device, errdir), nprocs=world, join=False)
+    try:
+        while not ctx.join(timeout=1.0):
+            if time.monotonic() - t0 > timeout_s:
+                alive = [i for i, p in enumerate(ctx.processes) if p.is_alive()]
+                for p in ctx.processes:
+                    if p.is_alive():
+                        p.kill()
+                failure = {"kind": "timeout", "rank": alive[0] if alive else None,
+                           "what": "rank(s) %s still running after %.0f s: killed" % (alive, timeout_s)}
+                break
+    except Exception as e:  # ProcessRaisedException / ProcessExitedException: mp has terminated the other ranks
+        failure = {"kind": type(e).__name__, "rank": getattr(e, "error_index", None),
+                   "what": str(e).strip().splitlines()[-1][:300] if str(e).strip() else repr(e)}
+
+    def tail(rank, n=25):
+        try:
+            return open(os.path.join(errdir, "rank%d.err" % rank), errors="replace").read().splitlines()[-n:]
+        except OSError:
+            return []
+
+    rc = 0
+    if failure is None:
+        for r in range(world):  # nothing a rank said is lost
+            for line in tail(r, 10 ** 6):
+                print("[rank %d] %s" % (r, line), file=sys.stderr)
+    else:
+        r = failure["rank"] if failure["rank"] is not None else 0
+        print(json.dumps({"metric": "bench.py --gpus %d (self-launched ranks)" % world, "value": None, "n_gpus": world,
+                          "error": failure["what"], "error_kind": failure["kind"], "failed_rank": failure["rank"],
+                          "stderr_tail": tail(r), "other_ranks_stderr_tail": {str(o): tail(o, 5) for o in range(world) if o != r},
+                          "elapsed_s": time.monotonic() - t0}), flush=True)
+        rc = 1
+    shutil.rmtree(errdir, ignore_errors=True)
+    return rc
 
 
 def main(argv=None, backend="nccl", make_step=None, device=None):
@@ -298,6 +374,11 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                     help="with ONE rank: still create the process group and wrap the train model in DDP, so that the "
                          "collectives of the N > 1 path run through RCCL on a single GPU (a test of the plumbing, not a "
                          "measurement)")
+    ap.add_argument("--config", default=None, help="--mode train: one of the reference's YAML files (configs/config*.yaml): "
+                                                   "its train.batchsize, learning rate, schedule, clip and loss weights")
+    ap.add_argument("--opts", default=[], nargs="+", help="key value overrides of the config (ddp-train.py:596)")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0,
+                    help="self-launched ranks (--gpus N without a launcher) are killed after this many seconds")
     ap.add_argument("--mode", default="march", choices=["march", "train"],
                     help="march (default, the contract metric + a `train` object); train: only the training loop, as "
                          "the headline value (iterations/s)")
@@ -305,7 +386,11 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks here, as the reference starts its own (ddp-train.py:612-625)
-        return self_launch(list(sys.argv[1:] if argv is None else argv), args.gpus, backend, make_step, device)
+        rc = self_launch(list(sys.argv[1:] if argv is None else argv), args.gpus, backend, make_step, device,
+                         timeout_s=args.launch_timeout)
+        if rc:
+            raise SystemExit(rc)
+        return
     rank, local_rank, world = env_ranks()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE=%d)" % (args.gpus, world, world))
@@ -319,8 +404,12 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     dist = init_process_group(backend, rank, world, dev, force=args.dist_smoke)
 
     if args.mode == "train":
+        cfg = None
+        if args.config:
+            from ava256_amd.config import load_train_config
+            cfg = load_train_config(args.config, args.opts)
         t = train_leg(args.workload, args.steps, args.warmup, rank, local_rank, world, dev, dist,
-                      with_bg=args.workload != "C2", ddp=(world > 1 or args.dist_smoke))
+                      with_bg=args.workload != "C2", ddp=(world > 1 or args.dist_smoke), config=cfg)
         if rank == 0:
             print(json.dumps({
                 "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",
@@ -357,6 +446,8 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         ev1.record()
         torch.cuda.synchronize(dev)
         render_ms = ev0.elapsed_time(ev1) / 5
+    if gpu and "hit_packets_fn" in info and not args.no_render:
+        info["hit_packets"] = info["hit_packets_fn"]()
     fused_ms = None
     if gpu and "fused_step" in info and not args.no_render:  # the training step with row N1's fusion (extra field as well)
         for _ in range(2):
@@ -426,12 +517,15 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             # per-launch HBM bytes from separate rocprofv3 PMC passes (tools/make_traffic.py): a RECORDED measurement,
             # stamped with the commit it was taken at -- this run did not collect counters
             traffic = traffic_at = None
+            traffic_fwd = valu = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
                     doc = json.load(open(tf))
                     traffic = doc.get(args.workload, {}).get(dom)
+                    traffic_fwd = doc.get(args.workload, {}).get("march_forward")
                     traffic_at = doc.get("_measured_at_commit")
+                    valu = doc.get("valu", {}).get(args.workload)
                 except Exception:
                     traffic = None
             out["fwd_rays_per_s"] = (info["n_local"] * H * W) / (kavg["march_forward"] * 1e-3) if "march_forward" in kavg else None
@@ -447,13 +541,29 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_measured_at_commit": traffic_at,
                                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                               "traffic_ratio": (traffic / dom_bytes) if traffic else None,
                                "fwd": {"achieved": bf / (kavg.get("march_forward", float("nan")) * 1e-3) / 1e9,
                                        "algorithmic_bytes_per_launch": bf,
-                                       "avg_launch_ms": kavg.get("march_forward")}}
+                                       "avg_launch_ms": kavg.get("march_forward"), "traffic": traffic_fwd,
+                                       "traffic_ratio": (traffic_fwd / bf) if traffic_fwd else None}}
+            if valu:
+                # What binds these kernels is not HBM (frac above) but VALU issue + latency: recorded SQ counters of the
+                # same evidence run as `traffic` (tools/make_traffic.py; same commit stamp), per launch of each kernel.
+                hp = info.get("hit_packets")
+                out["roofline"]["valu"] = {
+                    "what": "busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles); wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; "
+                            "wave_insts = SQ_INSTS_VALU per launch; recorded counter passes (traffic_measured_at_commit)",
+                    "kernels": {k: dict(v, wave_insts_per_hit_packet=(v["wave_insts"] / hp) if hp else None)
+                                for k, v in valu.items()},
+                    "hit_packets_per_launch": hp}
         if train is not None:
             out["train"] = train
         if gpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(info["N"], H, W, K, slab)
+            # SURVEY.md 8(d) names C1 (the reference's own CPU-runnable configuration: 4 cameras, 128x128, K=512) as the
+            # second CPU timing: all four cameras, a few seconds
+            c1 = WORKLOADS["C1"]
+            out["cpu_baseline"]["C1"] = cpu_baseline(c1[0], c1[1], c1[2], c1[3], c1[4], budget_s=4.0, cams=c1[0])
             out["reference_cpu"] = REFERENCE_CPU
         print(json.dumps(out), flush=True)
     if dist is not None:

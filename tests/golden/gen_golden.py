@@ -211,7 +211,12 @@ if __name__ == "__main__":
     save_march("march_k64_m4", N=2, H=13, W=13, k3=4, M=4, fadescale=8.0, fadeexp=8.0)
     # dense opacity: most rays saturate -> exercises the raysat backward rule (primaccum.h:86-93)
     save_march("march_k8_m8_sat", N=1, H=15, W=15, k3=2, M=8, fadescale=8.0, fadeexp=8.0, alpha_shift=-1.0)
-    # K = 125: not a power of two (leaves on two levels of the implicit heap), general fade (pow / exp path), thin opacity
+    # K = 125: not a power of two (leaves on two levels of the implicit heap), general fade (pow / exp path), thin opacity.
+    # What this fixture CANNOT pin: composition ORDER.  The dense statement composites in ascending k, the kernels (and the
+    # reference's CUDA traversal) in DFS-leaf order, which differs from ascending k exactly when K is not a power of two
+    #  -- so the scene has to stay unsaturated (alpha <= 0.08: additive accumulation commutes).
+    # Order under saturation at K not in 2^m rests on the oracle-vs-HIP scenes (K = 37, 300 in tests/test_gpu_parity.py:
+    # SCENES), whose oracle walks the reference's DFS (oracle/mvp_oracle.c: traverse).
     save_march("march_k125_m4_fade", N=1, H=13, W=13, k3=5, M=4, fadescale=4.0, fadeexp=3.0, alpha_shift=6.0)
     # warp-field sampler (mvpraymarch.py:762-774: dowarp=True, algo=1), warp grid M/2
     save_march("march_warp_k8_m8", N=2, H=15, W=15, k3=2, M=8, fadescale=6.5, fadeexp=7.5, dowarp=True)

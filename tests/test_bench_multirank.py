@@ -109,6 +109,57 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path, monkeypatch, ca
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 2 * 3 * 16 * 16) <= 1e-6 * 2 * 3 * 16 * 16
 
 
+def _failing_step_factory(args, rank, world, dev):
+    """Rank 1 dies while it builds its step (what a rank that cannot open its GPU, or runs out of memory, looks like)."""
+    if rank == 1:
+        print("RCCL-like diagnostic line of rank 1", file=sys.stderr)
+        raise RuntimeError("rank 1 cannot make its step")
+    return _oracle_step_factory(args, rank, world, dev)
+
+
+def _hanging_step_factory(args, rank, world, dev):
+    import time
+    if rank == 0:
+        time.sleep(3600)
+    return _oracle_step_factory(args, rank, world, dev)
+
+
+def _launch(monkeypatch, capfd, factory, extra=()):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("OMP_NUM_THREADS", "2")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    import bench
+    capfd.readouterr()
+    rc = 0
+    try:
+        bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "C1", "--cams", "3"] + list(extra),
+                   backend="gloo", make_step=factory, device="cpu")
+    except SystemExit as e:
+        rc = e.code
+    lines = [l for l in capfd.readouterr().out.strip().splitlines() if l.startswith("{")]
+    return rc, lines
+
+
+def test_self_launch_reports_a_failed_rank_in_its_own_format(monkeypatch, capfd):
+    """The first multi-GPU run this repository is ever offered must fail loudly and legibly: a rank that raises gives ONE
+    JSON line with "error", the failing rank and the tail of ITS stderr, and a non-zero exit status -- not a traceback of
+    the parent and no line."""
+    rc, lines = _launch(monkeypatch, capfd, _failing_step_factory)
+    assert rc == 1 and len(lines) == 1, (rc, lines)
+    j = json.loads(lines[0])
+    assert j["value"] is None and j["n_gpus"] == 2 and j["failed_rank"] == 1
+    assert "cannot make its step" in j["error"] or any("cannot make its step" in l for l in j["stderr_tail"])
+    assert any("RCCL-like diagnostic line" in l for l in j["stderr_tail"])      # what the rank wrote to fd 2 is there
+
+
+def test_self_launch_kills_hung_ranks(monkeypatch, capfd):
+    rc, lines = _launch(monkeypatch, capfd, _hanging_step_factory, extra=["--launch-timeout", "20"])
+    assert rc == 1 and len(lines) == 1, (rc, lines)
+    j = json.loads(lines[0])
+    assert j["error_kind"] == "timeout" and j["value"] is None and "killed" in j["error"]
+
+
 import pytest  # noqa: E402
 
 

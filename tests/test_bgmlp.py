@@ -104,8 +104,10 @@ def _check_fused_against(fixture):
         if not g.has("grad/" + k):
             continue
         ref = g["grad/" + k].reshape(v.shape)
-        assert _cos(v, ref) >= 0.99, (k, _cos(v, ref))
-        assert np.linalg.norm(v - ref) <= 0.15 * np.linalg.norm(ref), (k, np.linalg.norm(v - ref) / np.linalg.norm(ref))
+        # what bf16 operands cost (a pre-activation rounded across zero flips its LeakyReLU slope): measured on the MI355X
+        # cos 0.996 / 9 % norm-wise in the first layers (eager bf16 autocast: 0.993 / 12 %); bounds = measured + margin
+        assert _cos(v, ref) >= 0.994, (k, _cos(v, ref))
+        assert np.linalg.norm(v - ref) <= 0.11 * np.linalg.norm(ref), (k, np.linalg.norm(v - ref) / np.linalg.norm(ref))
 
 
 @pytest.mark.gpu

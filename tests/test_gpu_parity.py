@@ -187,6 +187,9 @@ def test_non_cubic_slabs_and_general_fade(ops, oracle64, shape, fadescale, fadee
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), str(shape))
 
 
+FUZZ_ESCAPES = []   # (seed, which bound) of the draws that needed the fp32-oracle criterion (see the test below them)
+
+
 def fuzz_draw(seed, oracle64):
     """The seeded random configuration of test_randomized_configurations (also replayed by tools/debug_fuzz.py)."""
     from ava256_amd.scene import make_scene
@@ -276,6 +279,8 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
             if over.max() > 0:
                 # as below: acceptable only where plain fp32 (the oracle's f32 build, same raysat and gradients) is
                 # further from float64 on that very primitive (huge boxes: hundreds of samples per ray and primitive)
+                FUZZ_ESCAPES.append((seed, "per-primitive " + name))
+                print("fuzz escape hatch taken:", cfg, name)
                 if e32 is None:
                     r32 = oracle32.march_backward(*a, ref_sat, g2, fadescale=fadescale, fadeexp=fadeexp, warp=warp)
                     e32 = np.abs(r32[3].reshape(N * K, -1, 4) - rgt.reshape(N * K, -1, 4))
@@ -288,6 +293,8 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
         try:
             _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), cfg)
         except AssertionError:
+            FUZZ_ESCAPES.append((seed, "standing bounds"))
+            print("fuzz escape hatch taken:", cfg)
             # Over the standing bound: acceptable only where fp32 itself is the limit (a few huge boxes, hundreds of
             # samples per ray and primitive) -- the same march in plain fp32 (the reference's arithmetic; the oracle's
             # f32 build, same raysat and gradients) must then be further from float64 than the kernel is.
@@ -300,6 +307,16 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
     if warp is not None:  # a position gradient like the pose gradients (see the warp-field tests below for the bounds)
         gw, rgw = grads["warp"], ref[4]
         assert cosine(gw, rgw) >= POSE_COS and np.linalg.norm(gw - rgw) <= 2e-2 * np.linalg.norm(rgw), (cfg, cosine(gw, rgw))
+
+
+def test_fuzz_escape_hatch_is_not_taken_on_the_default_seeds():
+    """test_randomized_configurations lets a draw exceed the standing bounds when the oracle's own fp32 build is 1.5 x worse
+    still -- honest (fp32 is then the limit), but an escape hatch: it is counted, printed, and on the default 24 seeds it
+    must not be taken at all.  (Runs after the draws: same module, file order.  With MVP_FUZZ_SEEDS / MVP_FUZZ_FIRST set
+    the count is only reported: one draw in ~500 takes it)"""
+    print("fuzz escape hatch taken %d times: %s" % (len(FUZZ_ESCAPES), FUZZ_ESCAPES))
+    if "MVP_FUZZ_SEEDS" not in os.environ and "MVP_FUZZ_FIRST" not in os.environ:
+        assert FUZZ_ESCAPES == [], FUZZ_ESCAPES
 
 
 @pytest.mark.parametrize("mode", BACKWARD_MODES)

@@ -275,3 +275,34 @@ def test_training_through_the_kernels_reduces_the_loss():
     assert np.isfinite(last) and last < 0.8 * first, (first, last)
     for p in tr.params:
         assert torch.isfinite(p).all()
+
+
+def test_config_reader_takes_the_references_keys(tmp_path):
+    """ava-256_amd/config.py reads the keys ddp-train.py reads from configs/config*.yaml (:78,82,321,404-430,441) into the
+    Trainer's arguments; `--opts`-style overrides; unknown loss terms are rejected, other sections ignored.  With the
+    reference mounted (build container) its own three files are read as well."""
+    import os
+    from ava256_amd.config import load_train_config
+    from ava256_amd.trainloop import Trainer
+    y = tmp_path / "c.yaml"
+    y.write_text("device: cuda\ntrain:\n  dataset_dir: /x\n  nids: 4\n  init_learning_rate: 3.0e-4\n  lr_scheduler_iter: 5_000\n"
+                 "  gamma: 1.2\n  batchsize: 6\n  clip: 0.5\n  losses:\n    irgbl1: 1.0\n    primvolsum: 0.02\n"
+                 "progress:\n  output_path: run/\n")
+    c = load_train_config(str(y))
+    assert c["trainer"] == {"lr": 3.0e-4, "lr_scheduler_iter": 5000, "gamma": 1.2, "clip": 0.5,
+                            "loss_weights": {"irgbl1": 1.0, "primvolsum": 0.02}}
+    assert c["batchsize"] == 6 and c["nids"] == 4 and c["other"]["dataset_dir"] == "/x" and "progress" in c["other"]
+    c2 = load_train_config(str(y), ["train.clip", "2.0", "train.losses.kldiv", "1e-3"])
+    assert c2["trainer"]["clip"] == 2.0 and c2["trainer"]["loss_weights"]["kldiv"] == 1e-3
+    tr = Trainer.from_config(torch.nn.Linear(2, 2), c)
+    assert tr.clip == 0.5 and tr.optim.param_groups[0]["lr"] == 3.0e-4 and tr.sched.step_size == 5000 and tr.sched.gamma == 1.2
+    assert tr.loss_weights == {"irgbl1": 1.0, "primvolsum": 0.02}
+    (tmp_path / "bad.yaml").write_text("train:\n  losses:\n    irgbl1: 1.0\n    vgg: 1.0\n")
+    with pytest.raises(NotImplementedError):
+        load_train_config(str(tmp_path / "bad.yaml"))
+    for name in ("config.yaml", "config-4.yaml", "config-256.yaml"):
+        p = os.path.join("/root/reference/configs", name)
+        if os.path.exists(p):
+            r = load_train_config(p)
+            assert r["trainer"]["lr"] == 2.0e-4 and r["trainer"]["clip"] == 1.0 and r["batchsize"] >= 1
+            assert set(r["trainer"]["loss_weights"]) <= {"irgbl1", "vertl1", "kldiv", "primvolsum"}

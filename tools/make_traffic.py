@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""tools/make_traffic.py <fetch_summary.csv> <write_summary.csv> [workload] -- derive profiles/traffic.json (per-launch HBM
+"""tools/make_traffic.py <fetch_summary.csv> <write_summary.csv> [workload [sq_summary.csv lds_summary.csv]] -- derive profiles/traffic.json (per-launch HBM
 bytes of the march kernels, read by bench.py for `roofline.traffic`) from the two separate rocprofv3 --pmc passes that
 tools/pmc.sh summarised, and STAMP it with the commit the passes were measured at (run this in the build container
 right after the gpurun call returned, before the kernels change again).  bench.py prints the stamp next to the number.
 
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
-(MI355X_MICROARCH.md, "HBM"); both counters are in units of 1024 B."""
+(MI355X_MICROARCH.md, "HBM"); both counters are in units of 1024 B.
+
+With the SQ pass (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_WAIT_ANY) and the pass that holds GRBM_GUI_ACTIVE
+(the kernel's duration in shader-clock cycles), a "valu" object is recorded as well -- what actually binds these kernels:
+  busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles)   (the counter ticks in quad-cycles, per SIMD, summed)
+  wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES                              (share of a wave's life spent in s_waitcnt)
+  wave_insts = SQ_INSTS_VALU per launch (wave-level VALU instructions)."""
 import json
 import os
 import subprocess
@@ -40,6 +46,15 @@ def main():
     doc["_measured_at_commit"] = head + ("+uncommitted kernel changes" if dirty else "")
     doc["_sources"] = [os.path.relpath(os.path.abspath(p), ROOT) for p in (fetch, write)]
     doc[workload] = {k: (2.0 * f[k] + w[k]) * 1024.0 for k in sorted(f) if k in w}
+    if len(sys.argv) > 5:
+        sq, lds = sys.argv[4], sys.argv[5]
+        ctr = lambda path, name: per_dispatch(path, name)
+        insts, active, wcyc, wait = (ctr(sq, c) for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"))
+        cyc = {k: v / 8.0 for k, v in ctr(lds, "GRBM_GUI_ACTIVE").items()}  # (the counter is summed over the 8 XCDs)
+        doc.setdefault("valu", {})[workload] = {
+            k: {"wave_insts": insts[k], "busy": active[k] * 4.0 / (1024.0 * cyc[k]), "wait": wait[k] / wcyc[k],
+                "kernel_cycles": cyc[k]} for k in sorted(insts) if k in active and k in cyc and k in wcyc and k in wait}
+        doc["_sources"] += [os.path.relpath(os.path.abspath(p), ROOT) for p in (sq, lds)]
     json.dump(doc, open(tf, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
