@@ -301,7 +301,11 @@ __device__ __forceinline__ bool packet_hits_box(const PacketBounds &pb, float x0
     axis_clip(pb.ax, x0, x1, tn, tf);
     axis_clip(pb.ay, y0, y1, tn, tf);
     axis_clip(pb.az, z0, z1, tn, tf);
-    return tn <= tf + 1e-4f + 1e-5f * fabsf(tf);
+    // A box whose six corner coordinates are all NaN (primscale = 0 under an axis-aligned rotation: inf * 0 in
+    // primtransf.h:12-63) is never entered by the reference: max_component / min_component of three NaN axes are NaN and the
+    // comparison fails (utils.h:659-665,679-685).  A NaN axis next to a valid one is ignored there, as the clips above do.
+    const bool all_nan = (x0 != x0) && (x1 != x1) && (y0 != y0) && (y1 != y1) && (z0 != z0) && (z1 != z1);
+    return tn <= tf + 1e-4f + 1e-5f * fabsf(tf) && !all_nan;
 }
 
 __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d) {
@@ -2585,7 +2589,17 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     if (tl < 15) {
         const float *Rg = p.primrot + pkl * 9, *sg = p.primscale + pkl * 3;
         const float *A = s_red + 48, *C = s_red + 51;  // A[j] = sum gy_j ; C[i*3+j] = sum xmt_i * gy_j
-        if (tl < 9) {
+        // No sample evaluated (all twelve sums are exact zeros): the reference adds nothing (primtransf.h:155-179 runs only
+        // when a lane evaluated, subset_kernel.h:203-205) -- in particular not 0 * NaN for a primitive whose transform is
+        // not finite and which therefore can never be sampled.
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) any = any || (s_red[48 + j] != 0.f);
+        if (!any) {
+            if (tl < 9) p.grad_primrot[pkl * 9 + tl] = 0.f;
+            else if (tl < 12) p.grad_primscale[pkl * 3 + tl - 9] = 0.f;
+            else p.grad_primpos[pkl * 3 + tl - 12] = 0.f;
+        } else if (tl < 9) {
             p.grad_primrot[pkl * 9 + tl] = sg[tl % 3] * C[tl];  // xmt_i * (gy_j * s_j)
         } else if (tl < 12) {
             const int j = tl - 9;  // sum_i R[i][j] * C[i][j] = sum rxmt_j * gy_j

@@ -335,8 +335,8 @@ def test_c2_full_batch_backward(c2_scene):
     """The bench's own launch, checked: forward + backward over all 80 cameras in ONE call (ten images per XCD, 327 680
     workgroups in the primitive-centric grid).  No primitive leaves the primitive-centric path (flags & 7 == 0), every
     gradient finite, Euler homogeneity over the whole batch, bit-reproducible slab gradient, and the gradients of image 0
-    and of image 79 equal to those of the same camera run alone (slab gradient bit for bit: integer sums whose rounds
-    do not depend on the batch; pose gradients to fp32 round-off)."""
+    and of image 79 equal to those of the same camera run alone (slab gradient: colour channels bit for bit, opacity to
+    the quantum of its batch-dependent scale; pose gradients to fp32 round-off)."""
     import ava256_amd as ops
     from ava256_amd import _hooks
     s = c2_scene
@@ -362,6 +362,11 @@ def test_c2_full_batch_backward(c2_scene):
     del grads2
     for n in (0, 79):
         _, g1 = _render(ops, s, slice(n, n + 1), grad=True, gout=gout[n:n + 1])
-        assert torch.equal(g1["template"][0], gt[n]), n
+        # colour channels: integer sums whose scale (round's sample count, its packets' max |g|, the slab's max opacity)
+        # does not depend on the batch -> bit for bit.  Opacity channel: its scale contains max |raysat| over the WHOLE
+        # launch (one word, written by the forward), so the same sums are rounded on a slightly different grid: 1e-4.
+        assert torch.equal(g1["template"][0][..., :3], gt[n][..., :3]), n
+        da = (g1["template"][0][..., 3] - gt[n][..., 3]).abs().max().item()
+        assert da <= 1e-4 * gt[n][..., 3].abs().max().item(), (n, da)   # (measured 3.2e-5)
         for k in ("primpos", "primrot", "primscale"):
             assert (g1[k][0] - grads[k][n]).abs().max().item() <= 1e-4 * grads[k][n].abs().max().item(), (n, k)
