@@ -1881,6 +1881,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     const uint32_t *aux_n = p.rayaux + img * 4;
     const int sW = 1, sH = TW, sD = TH * TW;  // voxel strides of the template slab
     const float mx = 0.5f * (float)(TW - 1), my = 0.5f * (float)(TH - 1), mz = 0.5f * (float)(TD - 1);
+    const float nfs_log2e = -p.fadescale * 1.44269504088896341f;  // exp(-fadescale * e) = exp2(nfs_log2e * e): one multiply
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
@@ -2322,7 +2323,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                     f3 ypow;
                     if (FADE8) {
                         const f3 y2 = y * y, y4 = y2 * y2;
-                        fade = fast_exp(-p.fadescale * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
+                        fade = fast_exp2(nfs_log2e * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));  // exp(-fadescale * sum y^8)
                         ypow = y4 * y2 * y;
                     } else {
                         const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
@@ -2333,9 +2334,9 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                                    fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
                                    fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
                     }
-                    const float ix = (y.x + 1.f) * 0.5f * (float)(TW - 1);
-                    const float iy = (y.y + 1.f) * 0.5f * (float)(TH - 1);
-                    const float iz = (y.z + 1.f) * 0.5f * (float)(TD - 1);
+                    // (y + 1) / 2 * (T - 1) as ONE fma per axis (the forward's three roundings are not needed here: the
+                    //  gradient is that of the same trilinear polynomial, evaluated at a point 1 ulp away at most)
+                    const float ix = fmaf(y.x, mx, mx), iy = fmaf(y.y, my, my), iz = fmaf(y.z, mz, mz);
                     // base corner kept in float, weights exact, ONE conversion per offset (see tri_setup_f)
                     const float fx0 = fminf(floorf(ix), (float)(TW - 2)), fy0 = fminf(floorf(iy), (float)(TH - 2)),
                                 fz0 = fminf(floorf(iz), (float)(TD - 2));
@@ -2398,12 +2399,20 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                     MVP_DOT4(d110, c110)
                     MVP_DOT4(d111, c111)
 #undef MVP_DOT4
-                    gy.x += mx * (wyz00 * (d001 - d000) + wyz10 * (d011 - d010) + wyz01 * (d101 - d100) +
-                                  wyz11 * (d111 - d110));
-                    gy.y += my * (wx0 * wz0 * (d010 - d000) + wx1 * wz0 * (d011 - d001) + wx0 * wz1 * (d110 - d100) +
-                                  wx1 * wz1 * (d111 - d101));
-                    gy.z += mz * (wx0 * wy0 * (d100 - d000) + wx1 * wy0 * (d101 - d001) + wx0 * wy1 * (d110 - d010) +
-                                  wx1 * wy1 * (d111 - d011));
+                    // utils.h:592-642, d/d(position) of the trilinear form, as a lerp tree over the eight dotted corners: the x
+                    // differences of the four (y, z) edges give d/dx and the edge values, their y differences d/dy, the last
+                    // difference d/dz -- 22 instructions instead of the 35 of the three separate weighted sums (the same
+                    // polynomial; the kernel is bound by its VALU instruction count, profiles/r04_backward_experiments.json)
+                    {
+                        const float dx00 = d001 - d000, dx10 = d011 - d010, dx01 = d101 - d100, dx11 = d111 - d110;
+                        const float gix = fmaf(wyz11, dx11, fmaf(wyz01, dx01, fmaf(wyz10, dx10, wyz00 * dx00)));
+                        const float e00 = fmaf(wx1, dx00, d000), e10 = fmaf(wx1, dx10, d010);  // (y0,z0) (y1,z0)
+                        const float e01 = fmaf(wx1, dx01, d100), e11 = fmaf(wx1, dx11, d110);  // (y0,z1) (y1,z1)
+                        const float dy0 = e10 - e00, dy1 = e11 - e01;
+                        const float giy = fmaf(wz1, dy1, wz0 * dy0);
+                        const float giz = fmaf(wy1, dy1, e01) - fmaf(wy1, dy0, e00);
+                        gy.x = fmaf(mx, gix, gy.x), gy.y = fmaf(my, giy, gy.y), gy.z = fmaf(mz, giz, gy.z);
+                    }
                     // ---- utils.h:582-589 scatter, in fixed point (see the header of this kernel) ----
                     {
                         // scaled by powers of two (exact); pairs, so that weight x pair is one packed multiply
