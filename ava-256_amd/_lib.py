@@ -56,7 +56,12 @@ SIGNATURES["mvp_bgmlp_backward"] = (_c_int, [_c_int] * 2 + [_c_void_p] * 6 + [_c
 SIGNATURES["mvp_march_block_map"] = (_c_int, [_c_int] * 7 + [_c_void_p] * 2)
 # primlist_count, nprims | hist[257] | stream
 SIGNATURES["mvp_list_demand"] = (_c_int, [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p])
-ABI_VERSION = 11
+SIGNATURES["mvp_pixel_tail_blocks"] = (_c_int, [_c_int] * 2)
+# N,H,W | rayrgba,cw,cb,bg,target | irgbrec,ialpha,l1_partials | stream
+SIGNATURES["mvp_pixel_tail_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 8 + [_c_void_p])
+# N,H,W | rayrgba,cw,bg,target,irgbrec,g_irgbrec,g_ialpha,g_l1 | grad_rayrgba,grad_bg,cwcb_partials | stream
+SIGNATURES["mvp_pixel_tail_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 11 + [_c_void_p])
+ABI_VERSION = 12
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -69,6 +69,36 @@ def _nearest_two(points: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def assemble_template_eager(tex, opacity, nboxes, boxsize):
+    """The reference's statements for the decoder -> raymarch hand-off (what assemble.assemble_template fuses):
+    models/decoders/rgb.py:137-143 and geometry.py:183-185 (view / permute / reshape of the conv outputs into per-primitive
+    slabs) and assembler.py:261 (`cat([relu(rgb * 25 + 100), relu(alpha)], -1)`).  CPU path of the stand-in decoder."""
+    N, B = tex.shape[0], boxsize
+    nh = math.isqrt(nboxes)
+    rgb = tex.view(N, B, 3, nh, B, nh, B).permute(0, 3, 5, 1, 4, 6, 2).reshape(N, nboxes, B, B, B, 3)
+    alpha = opacity.view(N, B, 1, nh, B, nh, B).permute(0, 3, 5, 1, 4, 6, 2).reshape(N, nboxes, B, B, B, 1)
+    return torch.cat([torch.relu(rgb * 25.0 + 100.0), torch.relu(alpha)], dim=-1)
+
+
+class _FrameGain(torch.autograd.Function):
+    """template[b] = base * gain[b] (base: the shared slabs [K,s,s,s,4], gain [B]).  One broadcast kernel forward; backward
+    as two matrix-vector products over the incoming gradient seen as [B, M] -- g^T gain for the slabs, g base for the
+    gains -- each reading it once at HBM speed (rocBLAS gemv; plain autograd would make two full-size temporaries and two
+    reductions, and the [1,B] x [B,M] matrix product that hipBLASLt offers for the first is 13 x slower than the gemv:
+    1.6 ms against 0.12 ms at C3, gpurun_out/r04k)."""
+
+    @staticmethod
+    def forward(ctx, base, gain):
+        ctx.save_for_backward(base, gain)
+        return gain.view(-1, *([1] * base.dim())) * base[None]
+
+    @staticmethod
+    def backward(ctx, g):
+        base, gain = ctx.saved_tensors
+        g2 = g.reshape(g.shape[0], -1)
+        return torch.mv(g2.t(), gain).view_as(base), torch.mv(g2, base.reshape(-1))
+
+
 class CodeEncoderStandIn(nn.Module):
     """VAE bottleneck with the reference's squashing constants and sampling rule (models/bottlenecks/vae.py:22-58)."""
 
@@ -103,15 +133,27 @@ class SlabDecoderStandIn(nn.Module):
         self.register_buffer("base_rot", base["primrot"][0].clone())
         self.register_buffer("base_scale", base["primscale"][0].clone())
         g = torch.Generator().manual_seed(seed + 17)
-        # pre-activation slabs with the random-init statistics of the real decoder heads
-        self.rgb = nn.Parameter(torch.randn(K, slab, slab, slab, 3, generator=g))
-        self.alpha = nn.Parameter(alpha_init * (1.0 + 0.2 * torch.randn(K, slab, slab, slab, 1, generator=g)))
+        nh = math.isqrt(K)
+        # K a square (every shipped configuration: 256, 4096, 16384): the head holds what the reference's conv decoders
+        # emit -- a texture `tex [1, 3*slab, nh*slab, nh*slab]` and `opacity [1, slab, ...]` (models/decoders/rgb.py:137-143,
+        # geometry.py:183-185) -- and the slabs are made by the fused hand-off kernel (assemble.assemble_template, SURVEY 8f
+        # row N2; on CPU by the reference's own view / permute / relu / cat statements); a per-frame gain stands for the
+        # view / expression conditioning.  Other K: per-primitive slab parameters and a per-primitive gain, eager.
+        self.conv_layout = nh * nh == K
+        if self.conv_layout:
+            S = nh * slab
+            self.tex = nn.Parameter(torch.randn(1, 3 * slab, S, S, generator=g))          # pre-activation, random-init statistics
+            self.opacity = nn.Parameter(alpha_init * (1.0 + 0.2 * torch.randn(1, slab, S, S, generator=g)))
+            self.gain = nn.Linear(code_dim, 1)
+        else:
+            self.rgb = nn.Parameter(torch.randn(K, slab, slab, slab, 3, generator=g))
+            self.alpha = nn.Parameter(alpha_init * (1.0 + 0.2 * torch.randn(K, slab, slab, slab, 1, generator=g)))
+            self.gain = nn.Linear(code_dim, K)  # per-frame, per-primitive brightness (view / expression conditioning)
         self.pos_delta = nn.Parameter(torch.zeros(K, 3))
         self.rotvec = nn.Parameter(torch.zeros(K, 3))
         self.logscale = nn.Parameter(torch.zeros(K, 3))
-        self.gain = nn.Linear(code_dim, K)  # per-frame, per-primitive brightness (view / expression conditioning)
         with torch.no_grad():  # seeded like everything else: identical on every rank and in every process
-            self.gain.weight.copy_(0.01 * torch.randn(K, code_dim, generator=g))
+            self.gain.weight.copy_(0.01 * torch.randn(self.gain.weight.shape, generator=g))
             self.gain.bias.zero_()
         if geometry:
             # Guide mesh with one vertex per primitive (the shell points, in the millimetre units of the dataset);
@@ -123,6 +165,18 @@ class SlabDecoderStandIn(nn.Module):
             self.register_buffer("tri_idx", torch.cat([torch.arange(K)[:, None], nn2], dim=1))     # [K,3]
             self.register_buffer("tri_bar", torch.tensor([0.9, 0.05, 0.05]).expand(K, 3).clone())
             self.register_buffer("adaptwarps", torch.zeros(K))                                     # assembler.py:66
+            # The reference's placement maps (assembler.py:62-63 idxim / barim [1024,1024,3]) for the primitive counts whose
+            # centre grids it defines (256, 16384): every texel of a primitive's block carries that primitive's triangle.
+            # On the GPU the placement then runs as ONE kernel (placement.prim_placement) instead of the
+            # gather / multiply / sum chain below and its index_add backward.
+            from .placement import GRIDS
+            if K in GRIDS:
+                ny, nx, y0, sy, x0, sx = GRIDS[K]
+                T = 1024
+                yy, xx = torch.meshgrid(torch.arange(T), torch.arange(T), indexing="ij")
+                kmap = (torch.clamp(yy // sy, max=ny - 1) * nx + torch.clamp(xx // sx, max=nx - 1)).reshape(-1)
+                self.register_buffer("idxim", self.tri_idx[kmap].reshape(T, T, 3).to(torch.int32).contiguous(), persistent=False)
+                self.register_buffer("barim", self.tri_bar[kmap].reshape(T, T, 3).contiguous(), persistent=False)
             self.geo_head = nn.Linear(code_dim, K * 3)
             with torch.no_grad():
                 self.geo_head.weight.copy_(0.02 * torch.randn(K * 3, code_dim, generator=g))
@@ -156,11 +210,19 @@ class SlabDecoderStandIn(nn.Module):
         B = code.shape[0]
         sch = schedule or {}
         rw = min(max(float(sch.get("residuals_weight", 1.0)), 0.0), 1.0)     # assembler.py:241
-        gain = 1.0 + 0.1 * torch.tanh(self.gain(code))                      # [B,K]
-        rgb = torch.relu(self.rgb * 25.0 + 100.0)                            # assembler.py:261
-        alpha = torch.relu(self.alpha)
-        template = torch.cat([rgb[None] * gain[:, :, None, None, None, None],
-                              alpha[None].expand(B, -1, -1, -1, -1, -1)], dim=-1).contiguous()
+        gain = 1.0 + 0.1 * torch.tanh(self.gain(code))                      # [B,1] or [B,K]
+        if self.conv_layout:
+            if self.tex.is_cuda and self.tex.dtype == torch.float32:
+                from .assemble import assemble_template
+                base = assemble_template(self.tex, self.opacity, self.K, self.slab)          # [1,K,s,s,s,4], one kernel
+            else:
+                base = assemble_template_eager(self.tex, self.opacity, self.K, self.slab)
+            template = _FrameGain.apply(base[0], gain[:, 0])                                # [B,K,s,s,s,4]
+        else:
+            rgb = torch.relu(self.rgb * 25.0 + 100.0)                        # assembler.py:261
+            alpha = torch.relu(self.alpha)
+            template = torch.cat([rgb[None] * gain[:, :, None, None, None, None],
+                                  alpha[None].expand(B, -1, -1, -1, -1, -1)], dim=-1).contiguous()
         pos_res, rot_res, scale_res = 0.01 * self.pos_delta, 0.1 * self.rotvec, torch.exp(0.1 * self.logscale)
         if rw < 1.0:                                                          # assembler.py:242-245
             pos_res, rot_res, scale_res = pos_res * rw, rot_res * rw, scale_res * rw + (1.0 - rw)
@@ -171,7 +233,11 @@ class SlabDecoderStandIn(nn.Module):
             guide = geo
             if gt_geo is not None and sch.get("use_gt_geo", False):
                 guide = gt_geo * self.vertstd + self.vertmean                                # assembler.py:105-109
-            pm = (self.tri_bar[None, :, :, None] * guide[:, self.tri_idx]).sum(dim=2) / self.volradius
+            if guide.is_cuda and guide.dtype == torch.float32 and hasattr(self, "idxim"):
+                from .placement import prim_placement
+                pm, _, _ = prim_placement(guide.contiguous(), self.idxim, self.barim, self.volradius, self.K)
+            else:                                                                            # assembler.py:118-122,143
+                pm = (self.tri_bar[None, :, :, None] * guide[:, self.tri_idx]).sum(dim=2) / self.volradius
             with torch.no_grad():
                 aw = self._update_adaptwarps(pm, bool(sch.get("running_avg_scale", False)))
             primpos = (pm + pos_res[None]).contiguous()
@@ -304,9 +370,11 @@ class RaymarchTrainModel(nn.Module):
 
     def __init__(self, decoder: nn.Module, volradius: float = 256.0, dt: float = 1.0,
                  renderer: Optional[Callable] = None, colorcal: Optional[nn.Module] = None,
-                 bgmodel: Optional[nn.Module] = None, encoder: Optional[nn.Module] = None, fused_rays: bool = True):
+                 bgmodel: Optional[nn.Module] = None, encoder: Optional[nn.Module] = None, fused_rays: bool = True,
+                 fused_tail: bool = True):
         super().__init__()
         self.fused_rays = fused_rays  # rays made inside the forward march instead of the two statements
+        self.fused_tail = fused_tail  # colour calibration + matting + L1 sum as one kernel each way (csrc/pixeltail.hip)
         self.decoder = decoder
         self.encoder = encoder
         self.raymarcher = Raymarcher(volradius, dt)
@@ -315,12 +383,35 @@ class RaymarchTrainModel(nn.Module):
         self._renderer = renderer  # CPU tests inject a pure-torch stand-in; None = the gfx950 kernels
 
     def forward(self, camrot, campos, focal, princpt, pixelcoords, code, schedule=None, camindex=None, idindex=None,
-                bg=None, gt_verts=None, noise=None):
+                bg=None, gt_verts=None, noise=None, target=None):
+        """`target` (optional, the batch's image): lets the fused decode tail of the GPU path sum |irgbrec - image| in the
+        pass that writes irgbrec (returned as `irgbl1_sum`; the Trainer divides by the element count = mean_ell_1)."""
         self.last_schedule = schedule  # ddp-train.py:371-377; consumed by the decoder's geometry branch
         expr_mu = expr_logstd = None
         if self.encoder is not None:                                                 # autoencoder.py: VAE bottleneck
             code, expr_mu, expr_logstd = self.encoder(code, noise)
         decout = self.decoder(code, schedule=schedule, gt_geo=gt_verts)
+        have_idx = camindex is not None and idindex is not None
+        if (self._renderer is None and self.fused_tail and self.fused_rays and decout.get("warp") is None
+                and decout["template"].is_cuda):
+            # autoencoder.py:240-265 as two kernels: rays + march (rayrgba stays in the march's [N,H,W,4] layout), then
+            # colour calibration + matting + L1 sum in one pass (csrc/pixeltail.hip), whose backward hands the march its
+            # upstream gradient in that layout -- no NHWC <-> NCHW split, no eager per-pixel statements
+            from .mvpraymarch import mvpraymarch_from_cameras
+            from .pixeltail import decode_tail
+            rm = self.raymarcher
+            rayrgba = mvpraymarch_from_cameras(campos, camrot, focal, princpt, pixelcoords, rm.volume_radius, rm.dt,
+                                               (decout["primpos"], decout["primrot"], decout["primscale"]), decout["template"])
+            cw = cb = None
+            if self.colorcal is not None and have_idx:                               # colorcal.py:28-30
+                cw = self.colorcal.wcam[camindex] + self.colorcal.wident[idindex]
+                cb = self.colorcal.bcam[camindex] + self.colorcal.bident[idindex]
+            if bg is None and self.bgmodel is not None and have_idx:
+                bg = self.bgmodel(camindex, idindex, self._samplecoords(pixelcoords))
+            irgbrec, ialpha, l1sum = decode_tail(rayrgba, cw, cb, None if bg is None else bg.contiguous(), target)
+            return {"irgbrec": irgbrec, "ialpha": ialpha, "primscale": decout["primscale"], "bg": bg,
+                    "verts": decout.get("verts"), "expr_mu": expr_mu, "expr_logstd": expr_logstd,
+                    "irgbl1_sum": l1sum if target is not None else None}
         if self._renderer is not None:
             rayrgb, rayalpha = self._renderer(camrot, campos, focal, princpt, pixelcoords, decout)
         elif self.fused_rays and decout.get("warp") is None:
@@ -329,17 +420,20 @@ class RaymarchTrainModel(nn.Module):
             raypos, raydir, tminmax = compute_raydirs(campos, camrot, focal, princpt, pixelcoords,
                                                       self.raymarcher.volume_radius)
             rayrgb, rayalpha, _, _ = self.raymarcher(raypos, raydir, tminmax, decout)
-        have_idx = camindex is not None and idindex is not None
         if self.colorcal is not None and have_idx:                                   # autoencoder.py:254-256
             rayrgb = self.colorcal(rayrgb, camindex, idindex)
         if bg is None and self.bgmodel is not None and have_idx:                     # autoencoder.py:258-261
-            samplecoords = torch.cat([pixelcoords[..., :1] * 2 / (pixelcoords.shape[-2] - 1) - 1,
-                                      pixelcoords[..., 1:] * 2 / (pixelcoords.shape[-3] - 1) - 1], dim=-1)  # :231-237
-            bg = self.bgmodel(camindex, idindex, samplecoords)
+            bg = self.bgmodel(camindex, idindex, self._samplecoords(pixelcoords))
         if bg is not None:                                                           # autoencoder.py:263-265
             rayrgb = rayrgb + (1.0 - rayalpha) * bg
         return {"irgbrec": rayrgb, "ialpha": rayalpha, "primscale": decout["primscale"], "bg": bg,
                 "verts": decout.get("verts"), "expr_mu": expr_mu, "expr_logstd": expr_logstd}
+
+
+    @staticmethod
+    def _samplecoords(pixelcoords):
+        return torch.cat([pixelcoords[..., :1] * 2 / (pixelcoords.shape[-2] - 1) - 1,
+                          pixelcoords[..., 1:] * 2 / (pixelcoords.shape[-3] - 1) - 1], dim=-1)   # autoencoder.py:231-237
 
 
 def forward_schedule(iternum: int) -> Dict[str, object]:
@@ -375,6 +469,8 @@ class Trainer:
         self.clip = clip
         self.loss_weights = dict(loss_weights or REFERENCE_LOSS_WEIGHTS)  # configs/config.yaml:17-21
         self.iternum = 0
+        import inspect
+        self._model_takes_target = "target" in inspect.signature(self.raw_model.forward).parameters
         self._clipper = None
         self.last_grad_norm = None
 
@@ -391,7 +487,10 @@ class Trainer:
         skipped, like a key absent from the reference's `loss_weights`."""
         out = {}
         if "irgbl1" in self.loss_weights:
-            out["irgbl1"] = mean_ell_1(output["irgbrec"], batch["image"])
+            if output.get("irgbl1_sum") is not None:   # summed by the fused decode tail in the pass that wrote irgbrec
+                out["irgbl1"] = output["irgbl1_sum"] / output["irgbrec"].numel()
+            else:
+                out["irgbl1"] = mean_ell_1(output["irgbrec"], batch["image"])
         if "vertl1" in self.loss_weights and output.get("verts") is not None and "verts" in batch:
             dec = self.raw_model.decoder
             out["vertl1"] = mean_ell_1(output["verts"], batch["verts"] * dec.vertstd + dec.vertmean)
@@ -410,7 +509,8 @@ class Trainer:
     def step(self, batch: Dict[str, torch.Tensor]):
         output = self.model(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
                             batch["code"], schedule=forward_schedule(self.iternum), camindex=batch.get("camindex"),
-                            idindex=batch.get("idindex"), gt_verts=batch.get("verts"), noise=batch.get("noise"))
+                            idindex=batch.get("idindex"), gt_verts=batch.get("verts"), noise=batch.get("noise"),
+                            **({"target": batch["image"]} if self._model_takes_target and "irgbl1" in self.loss_weights else {}))
         losses = self.losses(output, batch)
         loss = self.total_loss(losses)
         # single process: drop the gradients, so that backward hands each parameter its gradient tensor instead of

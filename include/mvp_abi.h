@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 11
+#define MVP_ABI_VERSION 12
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -131,6 +131,20 @@ int mvp_march_backward(int N, int H, int W, int K, const float *raypos, const fl
                        const float *grad_rayrgba, float *grad_primpos, float *grad_primrot, float *grad_primscale,
                        float *grad_tplate, float *grad_warp /*NULL iff warp is NULL*/, float fadescale,
                        float fadeexp, uint32_t *diag, void *stream);
+
+/* The decode tail and its image loss in one pass each way: colour calibration `w * image + b`
+ * (models/colorcals/colorcal.py:28-31, models/autoencoder.py:254-256), matting `rayrgb + (1 - rayalpha) * bg`
+ * (autoencoder.py:263-265) and sum |irgbrec - image| (losses.py:12-14, ddp-train.py:404-405), read from / written to the
+ * march's own layout rayrgba [N,H,W,4].  cw, cb [N,3] (both or neither), bg, target [N,3,H,W] may be NULL.  irgbrec
+ * [N,3,H,W] is bit-identical to the eager statements.  l1_partials [N * mvp_pixel_tail_blocks(H, W)] (NULL without a
+ * target) receives one partial sum per workgroup; cwcb_partials [N, blocks, 6] the partial sums of the gradients of
+ * (cw, cb).  g_l1: DEVICE scalar, the upstream gradient of the L1 sum (NULL = 0); g_irgbrec / g_ialpha may be NULL. */
+int mvp_pixel_tail_blocks(int H, int W);
+int mvp_pixel_tail_forward(int N, int H, int W, const float *rayrgba, const float *cw, const float *cb, const float *bg,
+                           const float *target, float *irgbrec, float *ialpha, float *l1_partials, void *stream);
+int mvp_pixel_tail_backward(int N, int H, int W, const float *rayrgba, const float *cw, const float *bg, const float *target,
+                            const float *irgbrec, const float *g_irgbrec, const float *g_ialpha, const float *g_l1,
+                            float *grad_rayrgba, float *grad_bg, float *cwcb_partials, void *stream);
 
 /* Demand statistics of the forward -> backward packet lists (no counterpart in the reference: its backward re-marches
  * every ray, mvpraymarch_subset_kernel.h:102-216).  `primlist_count` [nprims] as the grad-mode forward left it (the

@@ -102,7 +102,7 @@ def test_float64_replay_runs_on_cpu(oracle64, iternum):
     assert sorted(terms) == ["irgbl1", "kldiv", "primvolsum", "vertl1"] and np.isfinite(loss)
     assert _OracleMarch.last_stats["rays_hit"] > 0
     named = dict(tr.raw_model.named_parameters())
-    for n in ("decoder.rgb", "decoder.alpha", "decoder.gain.weight", "decoder.geo_head.weight", "colorcal.wcam",
+    for n in ("decoder.tex", "decoder.opacity", "decoder.gain.weight", "decoder.geo_head.weight", "colorcal.wcam",
               "encoder.mu.weight", "bgmodel.mlp.0.weight"):
         assert float(named[n].grad.abs().max()) > 0.0, n
     for n in ("decoder.pos_delta", "decoder.rotvec", "decoder.logscale"):   # residuals_weight = 0 switches them off
