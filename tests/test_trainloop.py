@@ -306,3 +306,18 @@ def test_config_reader_takes_the_references_keys(tmp_path):
             r = load_train_config(p)
             assert r["trainer"]["lr"] == 2.0e-4 and r["trainer"]["clip"] == 1.0 and r["batchsize"] >= 1
             assert set(r["trainer"]["loss_weights"]) <= {"irgbl1", "vertl1", "kldiv", "primvolsum"}
+
+
+def test_matrix_form_of_rodrigues_equals_the_per_element_form():
+    """trainloop.rodrigues_matrix (whole-matrix operations: an order of magnitude fewer kernels per training iteration) gives
+    the values of scene.rodrigues (the reference's per-element Rodrigues statements), at zero rotation too."""
+    from ava256_amd.scene import rodrigues
+    from ava256_amd.trainloop import rodrigues_matrix
+    g = torch.Generator().manual_seed(4)
+    v = torch.cat([0.7 * torch.randn(200, 3, generator=g, dtype=torch.float64), torch.zeros(3, 3, dtype=torch.float64)])
+    assert (rodrigues(v) - rodrigues_matrix(v)).abs().max().item() <= 1e-14
+    v32 = v.float().requires_grad_(True)
+    R = rodrigues_matrix(v32)
+    assert R.shape == (203, 3, 3) and torch.isfinite(R).all()
+    R.sum().backward()
+    assert torch.isfinite(v32.grad).all()
