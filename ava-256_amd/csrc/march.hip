@@ -308,10 +308,17 @@ __device__ __forceinline__ bool packet_hits_box(const PacketBounds &pb, float x0
     return tn <= tf + 1e-4f + 1e-5f * fabsf(tf) && !all_nan;
 }
 
-__device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d) {
+// same_o: every active ray of the packet starts at the same point (wave-uniform, decided once per packet): a pinhole
+// camera's rays do (utils_kernel.cu:30-32: raypos = campos / volradius), so the origin interval is that point and six of the
+// packet's fourteen wave reductions are not needed
+__device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d, bool same_o, float o_first) {
     AxisBounds a;
-    a.olo = uni(wave_min(active ? o : INFINITY));
-    a.ohi = uni(wave_max(active ? o : -INFINITY));
+    if (same_o) {
+        a.olo = a.ohi = o_first;
+    } else {
+        a.olo = uni(wave_min(active ? o : INFINITY));
+        a.ohi = uni(wave_max(active ? o : -INFINITY));
+    }
     const float ird = 1.0f / d;
     a.ilo = uni(wave_min(active ? ird : INFINITY));
     a.ihi = uni(wave_max(active ? ird : -INFINITY));
@@ -671,9 +678,13 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     if (__ballot(active) != 0ull) {
         // ---------------- packet bounds (6-step butterflies, once per packet) ----------------
         PacketBounds pb;
-        pb.ax = axis_bounds(active, o.x, d.x);
-        pb.ay = axis_bounds(active, o.y, d.y);
-        pb.az = axis_bounds(active, o.z, d.z);
+        // (the first ACTIVE lane's origin, and whether every active lane has it: one ballot)
+        const int fl = __ffsll((long long)__ballot(active)) - 1;
+        const f3 of = mk3(rl_f(o.x, fl), rl_f(o.y, fl), rl_f(o.z, fl));
+        const bool same_o = __ballot(active && (o.x != of.x || o.y != of.y || o.z != of.z)) == 0ull;
+        pb.ax = axis_bounds(active, o.x, d.x, same_o, of.x);
+        pb.ay = axis_bounds(active, o.y, d.y, same_o, of.y);
+        pb.az = axis_bounds(active, o.z, d.z, same_o, of.z);
         pb.tlo = uni(wave_min(active ? tmin : INFINITY));
         pb.thi = uni(wave_max(active ? tmax + 1e-5f : -INFINITY));
 
