@@ -273,6 +273,15 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
            "background_mlp": ("fused MFMA kernels (csrc/bgmlp.hip: bf16 operands, fp32 accumulation), %.1f GFLOP fwd per "
                               "iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
            if with_bg else "off (matting over a constant background)"}
+    if with_bg:  # MFMA utilisation of the dense kernels of this leg: a RECORDED counter pass (tools/make_mfma.py), not this run
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            rec = doc.get("mfma", {}).get(workload)
+            if rec:
+                out["mfma_frac"] = dict(rec, _what="SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the kernel, against the nominal "
+                                                   "peak; recorded pass of tools/evidence.sh", _source=doc.get("_mfma_source"))
+        except Exception:
+            pass
     del tr, model, batch
     torch.cuda.empty_cache()
     return out

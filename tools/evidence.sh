@@ -3,7 +3,8 @@
 # bench line, separate FETCH_SIZE / WRITE_SIZE / SQ / TA / LDS counter passes of the march kernels, and kernel stats + MFMA
 # counters of the train leg (C3: 4 frames, fused bf16 background MLP), the MLP and warp-field microbenchmarks.  Everything lands in gpurun_out/<tag>*/ ; copy what is to
 # be judged into profiles/ and run `python tools/make_traffic.py profiles/<tag>_pmc_fetch.csv profiles/<tag>_pmc_write.csv` in the
-# build container (it stamps traffic.json with the commit).
+# build container (it stamps traffic.json with the commit), with the SQ and LDS summaries as 4th / 5th argument for `roofline.valu`, and
+# `python tools/make_mfma.py profiles/<tag>_pmc_mfma.csv` for `train.C3.mfma_frac`.
 set -u
 TAG=$1
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p $O
