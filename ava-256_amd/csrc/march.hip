@@ -220,6 +220,30 @@ __device__ __forceinline__ RecP recp_of(const Rec &q) {
 // compositing.
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+// Packed multiply / fma with ONE element of a register pair broadcast to both lanes through the instruction's op_sel bits
+// (VOP3P: op_sel picks the source half of the low result lane, op_sel_hi that of the high one).  `a * splat(w)` written in C++
+// makes the compiler build a (w, w) pair with a v_mov per weight -- eight per sample in the backward's walk; with the weights
+// kept as the NATURAL pairs (w_x0, w_x1) * w_yz that four packed multiplies deliver, no pair has to be built at all.
+__device__ __forceinline__ v2f pk_mul_lo(v2f a, v2f w) {  // a * w.x
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+__device__ __forceinline__ v2f pk_mul_hi(v2f a, v2f w) {  // a * w.y
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_lo(v2f a, v2f w, v2f c) {  // a * w.x + c
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_hi(v2f a, v2f w, v2f c) {  // a * w.y + c
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
 
 // primtransf.h:119-132 for a direction (no translation) and for a point
 __device__ __forceinline__ Y3 box_dir(const RecP &q, v2f vxy, float vz) {
@@ -2351,9 +2375,9 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                     // base corner kept in float, weights exact, ONE conversion per offset (see tri_setup_f)
                     const float fx0 = fminf(floorf(ix), (float)(TW - 2)), fy0 = fminf(floorf(iy), (float)(TH - 2)),
                                 fz0 = fminf(floorf(iz), (float)(TD - 2));
-                    const float wx1 = ix - fx0, wx0 = 1.f - wx1;
-                    const float wy1 = iy - fy0, wy0 = 1.f - wy1;
-                    const float wz1 = iz - fz0, wz0 = 1.f - wz1;
+                    const float wx1 = ix - fx0, wy1 = iy - fy0, wz1 = iz - fz0;
+                    const v2f wxp = {1.f - wx1, wx1}, wyp = {1.f - wy1, wy1}, wzp = {1.f - wz1, wz1};  // (w_0, w_1) per axis
+                    const float wz0 = wzp.x;
                     const float vbf = fmaf(fz0, (float)sD, fmaf(fy0, (float)sH, fx0));  // (small integers: exact; sW = 1)
                     const int vb = (int)vbf;
                     // Corner values are kept as the (x,y) / (z,w) register pairs the 16-byte LDS reads deliver, so that
@@ -2370,13 +2394,19 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                     MVP_LOADC(c110, vb + sD + sH)
                     MVP_LOADC(c111, vb + sD + sH + sW)
 #undef MVP_LOADC
-                    const float wyz00 = wy0 * wz0, wyz10 = wy1 * wz0, wyz01 = wy0 * wz1, wyz11 = wy1 * wz1;
-                    const float w000 = wx0 * wyz00, w001 = wx1 * wyz00, w010 = wx0 * wyz10, w011 = wx1 * wyz10,
-                                w100 = wx0 * wyz01, w101 = wx1 * wyz01, w110 = wx0 * wyz11, w111 = wx1 * wyz11;
-                    const v2f vl = c000l * w000 + c001l * w001 + c010l * w010 + c011l * w011 + c100l * w100 +
-                                   c101l * w101 + c110l * w110 + c111l * w111;
-                    const v2f vh = c000h * w000 + c001h * w001 + c010h * w010 + c011h * w011 + c100h * w100 +
-                                   c101h * w101 + c110h * w110 + c111h * w111;
+                    // the eight corner weights as four natural pairs W_zy = (w_zy0, w_zy1): six packed multiplies, no (w, w) pairs
+                    const v2f wyzA = pk_mul_lo(wyp, wzp), wyzB = pk_mul_hi(wyp, wzp);  // (wyz00, wyz10), (wyz01, wyz11)
+                    const float wyz00 = wyzA.x, wyz10 = wyzA.y, wyz01 = wyzB.x, wyz11 = wyzB.y;
+                    const v2f W00 = pk_mul_lo(wxp, wyzA), W01 = pk_mul_hi(wxp, wyzA);  // (w000, w001), (w010, w011)
+                    const v2f W10 = pk_mul_lo(wxp, wyzB), W11 = pk_mul_hi(wxp, wyzB);  // (w100, w101), (w110, w111)
+                    v2f vl = pk_mul_lo(c000l, W00), vh = pk_mul_lo(c000h, W00);
+                    vl = pk_fma_hi(c001l, W00, vl), vh = pk_fma_hi(c001h, W00, vh);
+                    vl = pk_fma_lo(c010l, W01, vl), vh = pk_fma_lo(c010h, W01, vh);
+                    vl = pk_fma_hi(c011l, W01, vl), vh = pk_fma_hi(c011h, W01, vh);
+                    vl = pk_fma_lo(c100l, W10, vl), vh = pk_fma_lo(c100h, W10, vh);
+                    vl = pk_fma_hi(c101l, W10, vl), vh = pk_fma_hi(c101h, W10, vh);
+                    vl = pk_fma_lo(c110l, W11, vl), vh = pk_fma_lo(c110h, W11, vh);
+                    vl = pk_fma_hi(c111l, W11, vl), vh = pk_fma_hi(c111h, W11, vh);
                     float4 v;
                     v.x = vl.x, v.y = vl.y, v.z = vh.x, v.w = vh.y;
                     const float alpha = v.w * fade;
@@ -2446,23 +2476,23 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         atomicAdd(Ap + (OFF_), fix_rn((x_ - (float)fix_rn(x_)) * res_mul));     \
     }
 #endif
-#define MVP_LSCATTER(FIX_, OFF_, WGT_)                              \
+#define MVP_LSCATTER(FIX_, OFF_, MUL_, WP_)                         \
     {                                                               \
-        const v2f a_ = qxy * (WGT_), b_ = qzw * (WGT_);             \
+        const v2f a_ = MUL_(qxy, WP_), b_ = MUL_(qzw, WP_);         \
         FIX_((OFF_), a_.x)                                          \
         FIX_((OFF_) + Vp, a_.y)                                     \
         FIX_((OFF_) + 2 * Vp, b_.x)                                 \
         FIX_((OFF_) + 3 * Vp, b_.y)                                 \
     }
 #define MVP_LSCATTER8(FIX_)                                         \
-    MVP_LSCATTER(FIX_, 0, w000)                                     \
-    MVP_LSCATTER(FIX_, 1, w001)                                     \
-    MVP_LSCATTER(FIX_, gH, w010)                                    \
-    MVP_LSCATTER(FIX_, gH + 1, w011)                                \
-    MVP_LSCATTER(FIX_, gD, w100)                                    \
-    MVP_LSCATTER(FIX_, gD + 1, w101)                                \
-    MVP_LSCATTER(FIX_, gD + gH, w110)                               \
-    MVP_LSCATTER(FIX_, gD + gH + 1, w111)
+    MVP_LSCATTER(FIX_, 0, pk_mul_lo, W00)                           \
+    MVP_LSCATTER(FIX_, 1, pk_mul_hi, W00)                           \
+    MVP_LSCATTER(FIX_, gH, pk_mul_lo, W01)                          \
+    MVP_LSCATTER(FIX_, gH + 1, pk_mul_hi, W01)                      \
+    MVP_LSCATTER(FIX_, gD, pk_mul_lo, W10)                          \
+    MVP_LSCATTER(FIX_, gD + 1, pk_mul_hi, W10)                      \
+    MVP_LSCATTER(FIX_, gD + gH, pk_mul_lo, W11)                     \
+    MVP_LSCATTER(FIX_, gD + gH + 1, pk_mul_hi, W11)
                         if (!RESID || !pass_b) {  // (workgroup-uniform; the residual scatter exists in RESID only)
                             MVP_LSCATTER8(MVP_FIX1)
                         } else {

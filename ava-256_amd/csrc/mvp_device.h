@@ -92,28 +92,41 @@ __device__ __forceinline__ int dpp_i(int i, int which) {
 #undef MVP_DPP_I
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// min / max over the wave in 6 fused DPP instructions + 1 v_readlane (idempotent operations only): an inclusive scan inside
+// every row of 16 lanes (row_shr 1, 2, 4, 8: lane 15 of a row ends up with the row's result; a lane without a source is
+// disabled and keeps its value), then row_bcast:15 (lane 15 of a row -> the next row; rows 1 and 3 take it) and row_bcast:31
+// (lane 31 -> rows 2 and 3): lane 63 holds the result.  The butterfly form (wave_sum below) costs 4 x (v_mov_dpp + op) + 4
+// v_readlane + 3 operations = 15 VALU instructions -- hipcc does not fold __builtin_amdgcn_update_dpp into the operation --
+// and the forward's exact test does two reductions per listed primitive, its packet bounds eight to fourteen per packet.
+// Written as one asm block: a DPP read of a VGPR the previous VALU instruction wrote needs two wait states (s_nop 1), which
+// the compiler's hazard recogniser does not insert inside inline assembly.  Every caller runs these with all 64 lanes
+// enabled (inactive rays pass neutral values).
+#define MVP_WAVE_SCAN(OPC_)                                                                    \
+    asm("s_nop 1\n\t" OPC_ " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"               \
+        "s_nop 1\n\t" OPC_ " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"               \
+        "s_nop 1\n\t" OPC_ " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"               \
+        "s_nop 1\n\t" OPC_ " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"               \
+        "s_nop 1\n\t" OPC_ " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"            \
+        "s_nop 1\n\t" OPC_ " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"            \
+        "s_nop 1"                                                                              \
+        : "+v"(v))
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v = fminf(v, dpp_f(v, w));
-    return fminf(fminf(rl_f(v, 0), rl_f(v, 16)), fminf(rl_f(v, 32), rl_f(v, 48)));
+    MVP_WAVE_SCAN("v_min_f32_dpp");
+    return rl_f(v, 63);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v = fmaxf(v, dpp_f(v, w));
-    return fmaxf(fmaxf(rl_f(v, 0), rl_f(v, 16)), fmaxf(rl_f(v, 32), rl_f(v, 48)));
+    MVP_WAVE_SCAN("v_max_f32_dpp");
+    return rl_f(v, 63);
 }
 __device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v = min(v, dpp_i(v, w));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    MVP_WAVE_SCAN("v_min_i32_dpp");
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v = max(v, dpp_i(v, w));
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    MVP_WAVE_SCAN("v_max_i32_dpp");
+    return __builtin_amdgcn_readlane(v, 63);
 }
+#undef MVP_WAVE_SCAN
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += dpp_f(v, w);
