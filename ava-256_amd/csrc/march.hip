@@ -36,6 +36,7 @@
 //     is kept as the always-correct fallback for primitives whose list overflowed (device-side flag).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "mvp_device.h"
 #include "mvp_host.h"
 
@@ -369,7 +370,7 @@ __device__ __forceinline__ float fade_pinned(f3 y, float fadescale, float fadeex
     } else {
         e = (fast_pow(fabsf(y.x), fadeexp) + fast_pow(fabsf(y.y), fadeexp)) + fast_pow(fabsf(y.z), fadeexp);
     }
-    return fast_exp(-fadescale * e);
+    return fast_exp2((-1.44269504088896341f * fadescale) * e);  // the scale product is loop-invariant: one multiply per sample
 }
 struct Tri {  // base corner (clamped so that all 8 corners are in bounds) and the 8 corner weights
     int x0, y0, z0;
@@ -396,22 +397,25 @@ __device__ __forceinline__ Tri tri_setup(f3 y, float mx, float my, float mz, int
 // ONCE.  Identical results, ~12 fewer instructions per sample, eight of them conversions.
 struct TriF {
     uint32_t off;  // byte offset of the base corner inside a TS^3 float4 slab
-    float w000, w001, w010, w011, w100, w101, w110, w111;
+    v2f W00, W01, W10, W11;  // the natural pairs W_zy = (w_zy0, w_zy1)
 };
+// Round 4: the index is ONE fma per axis (y * m/2 + m/2; the three-operation form (y + 1) * 0.5 * m it replaces differs by
+// <= 1 ulp of the index, and both forward sweeps call this one function, so they still agree bit for bit), and the eight
+// weights come out of six packed multiplies as the natural pairs (w_x0, w_x1) * w_yz -- the same products in the same order
+// as the scalar form, so the weights themselves are unchanged.
 template <int TS>
 __device__ __forceinline__ TriF tri_setup_f(f3 y) {
 #pragma clang fp contract(off)
-    constexpr float m = (float)(TS - 1), top = (float)(TS - 2);
-    const float ix = ((y.x + 1.f) * 0.5f) * m, iy = ((y.y + 1.f) * 0.5f) * m, iz = ((y.z + 1.f) * 0.5f) * m;
+    constexpr float h = 0.5f * (float)(TS - 1), top = (float)(TS - 2);
+    const float ix = __builtin_fmaf(y.x, h, h), iy = __builtin_fmaf(y.y, h, h), iz = __builtin_fmaf(y.z, h, h);
     const float fx0 = fminf(floorf(ix), top), fy0 = fminf(floorf(iy), top), fz0 = fminf(floorf(iz), top);
-    const float wx1 = ix - fx0, wx0 = 1.f - wx1;
-    const float wy1 = iy - fy0, wy0 = 1.f - wy1;
-    const float wz1 = iz - fz0, wz0 = 1.f - wz1;
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wz1 = iz - fz0;
+    const v2f wxp{1.f - wx1, wx1}, wyp{1.f - wy1, wy1}, wzp{1.f - wz1, wz1};
     TriF t;
     t.off = (uint32_t)__builtin_fmaf(fz0, (float)(TS * TS * 16), __builtin_fmaf(fy0, (float)(TS * 16), fx0 * 16.f));
-    const float wyz00 = wy0 * wz0, wyz10 = wy1 * wz0, wyz01 = wy0 * wz1, wyz11 = wy1 * wz1;
-    t.w000 = wx0 * wyz00, t.w001 = wx1 * wyz00, t.w010 = wx0 * wyz10, t.w011 = wx1 * wyz10;
-    t.w100 = wx0 * wyz01, t.w101 = wx1 * wyz01, t.w110 = wx0 * wyz11, t.w111 = wx1 * wyz11;
+    const v2f wyzA = pk_mul_lo(wyp, wzp), wyzB = pk_mul_hi(wyp, wzp);  // (wyz00, wyz10), (wyz01, wyz11)
+    t.W00 = pk_mul_lo(wxp, wyzA), t.W01 = pk_mul_hi(wxp, wyzA);        // (w000, w001), (w010, w011)
+    t.W10 = pk_mul_lo(wxp, wyzB), t.W11 = pk_mul_hi(wxp, wyzB);        // (w100, w101), (w110, w111)
     return t;
 }
 // sum_c w_c * corner_c on the (x,y)/(z,w) register pairs the 16-byte loads deliver, in corner order 000,001,..,111
@@ -430,6 +434,25 @@ __device__ __forceinline__ float4 tri_interp(const TRI &t, const float4 &c000, c
     vl = pk_fma(MVP_L(c101), splat(t.w101), vl), vh = pk_fma(MVP_H(c101), splat(t.w101), vh);
     vl = pk_fma(MVP_L(c110), splat(t.w110), vl), vh = pk_fma(MVP_H(c110), splat(t.w110), vh);
     vl = pk_fma(MVP_L(c111), splat(t.w111), vl), vh = pk_fma(MVP_H(c111), splat(t.w111), vh);
+#undef MVP_L
+#undef MVP_H
+    return make_float4(vl.x, vl.y, vh.x, vh.y);
+}
+
+// The same sum on the natural weight pairs: the op_sel broadcast forms above, no (w, w) pair is ever built
+__device__ __forceinline__ float4 tri_interp(const TriF &t, const float4 &c000, const float4 &c001, const float4 &c010,
+                                             const float4 &c011, const float4 &c100, const float4 &c101,
+                                             const float4 &c110, const float4 &c111) {
+#define MVP_L(C_) v2f{(C_).x, (C_).y}
+#define MVP_H(C_) v2f{(C_).z, (C_).w}
+    v2f vl = pk_mul_lo(MVP_L(c000), t.W00), vh = pk_mul_lo(MVP_H(c000), t.W00);
+    vl = pk_fma_hi(MVP_L(c001), t.W00, vl), vh = pk_fma_hi(MVP_H(c001), t.W00, vh);
+    vl = pk_fma_lo(MVP_L(c010), t.W01, vl), vh = pk_fma_lo(MVP_H(c010), t.W01, vh);
+    vl = pk_fma_hi(MVP_L(c011), t.W01, vl), vh = pk_fma_hi(MVP_H(c011), t.W01, vh);
+    vl = pk_fma_lo(MVP_L(c100), t.W10, vl), vh = pk_fma_lo(MVP_H(c100), t.W10, vh);
+    vl = pk_fma_hi(MVP_L(c101), t.W10, vl), vh = pk_fma_hi(MVP_H(c101), t.W10, vh);
+    vl = pk_fma_lo(MVP_L(c110), t.W11, vl), vh = pk_fma_lo(MVP_H(c110), t.W11, vh);
+    vl = pk_fma_hi(MVP_L(c111), t.W11, vl), vh = pk_fma_hi(MVP_H(c111), t.W11, vh);
 #undef MVP_L
 #undef MVP_H
     return make_float4(vl.x, vl.y, vh.x, vh.y);
