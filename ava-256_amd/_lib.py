@@ -37,6 +37,16 @@ SIGNATURES["mvp_march_forward_cams"] = (_c_int, [_c_int] * 4 + [_c_void_p] * 5 +
                                         [_c_void_p] * 2)
 SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
+# nh,B -> blocks | F,nh,B | tex,opacity,gain | tplate | stream | F,nh,B | tex,opacity,gain,grad_tplate | gtex,gop,partials | stream
+SIGNATURES["mvp_template_assemble_frames_blocks"] = (ctypes.c_longlong, [_c_int] * 2)
+SIGNATURES["mvp_template_assemble_frames_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
+SIGNATURES["mvp_template_assemble_frames_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 8)
+# N,K,rw | pos0,sn | rot0,sn | scale0,sn,sk,sc | posres,sn | rotres,sn | scaleres,sn | outputs / gradients | stream
+_POSE_IN = [_c_int, _c_int, ctypes.c_float, _c_void_p, ctypes.c_longlong, _c_void_p, ctypes.c_longlong, _c_void_p,
+            ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _c_void_p, ctypes.c_longlong, _c_void_p,
+            ctypes.c_longlong, _c_void_p, ctypes.c_longlong]
+SIGNATURES["mvp_prim_residuals_forward"] = (_c_int, _POSE_IN + [_c_void_p] * 4)
+SIGNATURES["mvp_prim_residuals_backward"] = (_c_int, _POSE_IN + [_c_void_p] * 9)
 # N,H,W | rayrgba | rayrgb,rayalpha | stream     and     N,H,W | g_rgb,g_alpha | g_rgba | stream
 SIGNATURES["mvp_rgba_split_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_void_p])
 SIGNATURES["mvp_rgba_split_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_void_p])
@@ -61,7 +71,7 @@ SIGNATURES["mvp_pixel_tail_blocks"] = (_c_int, [_c_int] * 2)
 SIGNATURES["mvp_pixel_tail_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 8 + [_c_void_p])
 # N,H,W | rayrgba,cw,bg,target,irgbrec,g_irgbrec,g_ialpha,g_l1 | grad_rayrgba,grad_bg,cwcb_partials | stream
 SIGNATURES["mvp_pixel_tail_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 11 + [_c_void_p])
-ABI_VERSION = 12
+ABI_VERSION = 13
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvp_gfx950.so")
-SOURCES = ["raydirs.hip", "aabb.hip", "march.hip", "assemble.hip", "placement.hip", "gradclip.hip", "bgmlp.hip", "pixeltail.hip", "abi_misc.hip"]
+SOURCES = ["raydirs.hip", "aabb.hip", "march.hip", "assemble.hip", "placement.hip", "gradclip.hip", "bgmlp.hip", "pixeltail.hip", "primpose.hip", "abi_misc.hip"]
 HEADERS = [os.path.join(CSRC, "mvp_device.h"), os.path.join(CSRC, "mvp_host.h"),
            os.path.join(ROOT, "include", "mvp_abi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize",

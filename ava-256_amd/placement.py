@@ -10,7 +10,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from ._tensors import require_device_f32
+from ._tensors import ptr, require_device_f32, stream_ptr
 
 # number of primitives -> (ny, nx, y0, sy, x0, sx): the centre grids of the two branches of the reference that also
 # define vcenterdu / vcenterdv (assembler.py:143-170 and :180-206); the others raise there (:217-224)
@@ -96,3 +96,86 @@ def prim_placement(geo, idxim, barim, volradius, nprims):
         raise RuntimeError("idxim must be an int32/int64 tensor on the GPU")
     _check_indices(idxim, geo.shape[1])
     return _Placement.apply(geo, _as_int32(idxim), barim, float(volradius), GRIDS[nprims])
+
+
+# ---- residual half of the hand-off (csrc/primpose.hip; assembler.py:241-253) ---------------------------------------------
+def _frames_or_shared(name, t, N, K, tail):
+    """[N, K, *tail] -> (tensor, frame stride in floats); [K, *tail] or [1, K, *tail] -> shared by the frames (stride 0)."""
+    t = require_device_f32(name, t.contiguous() if torch.is_tensor(t) else t)
+    per = 1
+    for d in tail:
+        per *= d
+    if tuple(t.shape) == (K,) + tail or tuple(t.shape) == (1, K) + tail:
+        return t, 0
+    if tuple(t.shape) == (N, K) + tail:
+        return t, K * per
+    raise RuntimeError("%s must be [N, K, %s] or [K, %s] (N = %d, K = %d), got %s"
+                       % (name, ", ".join(map(str, tail)), ", ".join(map(str, tail)), N, K, tuple(t.shape)))
+
+
+def _scale0_strides(scale0, N, K):
+    """Strides (frame, primitive, component) in floats of a base scale that broadcasts to [N, K, 3]."""
+    e = scale0.expand(N, K, 3) if scale0.dim() == 3 else scale0.reshape((1,) * (3 - scale0.dim()) + tuple(scale0.shape)).expand(N, K, 3)
+    return tuple(int(s) for s in e.stride())
+
+
+class _PrimResiduals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos0, rot0, scale0, posres, rotres, scaleres, rw, N, K):
+        pos0, pos0_sn = _frames_or_shared("pos0", pos0, N, K, (3,))
+        rot0, rot0_sn = _frames_or_shared("rot0", rot0, N, K, (3, 3))
+        posres, posres_sn = _frames_or_shared("posres", posres, N, K, (3,))
+        rotres, rotres_sn = _frames_or_shared("rotres", rotres, N, K, (3,))
+        scaleres, scaleres_sn = _frames_or_shared("scaleres", scaleres, N, K, (3,))
+        scale0 = scale0.detach()
+        if not scale0.is_cuda or scale0.dtype != torch.float32:
+            raise RuntimeError("scale0 must be a float32 tensor on the GPU")
+        ssn, ssk, ssc = _scale0_strides(scale0, N, K)
+        dev = pos0.device
+        primpos = torch.empty((N, K, 3), device=dev, dtype=torch.float32)
+        primrot = torch.empty((N, K, 3, 3), device=dev, dtype=torch.float32)
+        primscale = torch.empty((N, K, 3), device=dev, dtype=torch.float32)
+        ins = (N, K, float(rw), ptr(pos0), pos0_sn, ptr(rot0), rot0_sn, ptr(scale0), ssn, ssk, ssc, ptr(posres), posres_sn,
+               ptr(rotres), rotres_sn, ptr(scaleres), scaleres_sn)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().mvp_prim_residuals_forward(*ins, ptr(primpos), ptr(primrot), ptr(primscale),
+                                                                 stream_ptr(dev)), "mvp_prim_residuals_forward")
+        ctx.save_for_backward(pos0, rot0, scale0, posres, rotres, scaleres)
+        ctx.meta = (N, K, float(rw), pos0_sn, rot0_sn, (ssn, ssk, ssc), posres_sn, rotres_sn, scaleres_sn)
+        return primpos, primrot, primscale
+
+    @staticmethod
+    def backward(ctx, gpos, grot, gscale):
+        pos0, rot0, scale0, posres, rotres, scaleres = ctx.saved_tensors
+        N, K, rw, pos0_sn, rot0_sn, (ssn, ssk, ssc), posres_sn, rotres_sn, scaleres_sn = ctx.meta
+        dev = pos0.device
+
+        def dense(g, shape):  # an output nobody differentiated arrives as None
+            return torch.zeros(shape, device=dev, dtype=torch.float32) if g is None else g.contiguous().float()
+
+        gpos, grot, gscale = dense(gpos, (N, K, 3)), dense(grot, (N, K, 3, 3)), dense(gscale, (N, K, 3))
+        need = ctx.needs_input_grad
+        g_pos0 = torch.empty_like(pos0) if need[0] else None
+        g_rot0 = torch.empty_like(rot0) if need[1] else None
+        g_posres, g_rotres, g_scaleres = torch.empty_like(posres), torch.empty_like(rotres), torch.empty_like(scaleres)
+        ins = (N, K, rw, ptr(pos0), pos0_sn, ptr(rot0), rot0_sn, ptr(scale0), ssn, ssk, ssc, ptr(posres), posres_sn,
+               ptr(rotres), rotres_sn, ptr(scaleres), scaleres_sn)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().mvp_prim_residuals_backward(
+                *ins, ptr(gpos), ptr(grot), ptr(gscale), ptr(g_pos0) if g_pos0 is not None else None,
+                ptr(g_rot0) if g_rot0 is not None else None, ptr(g_posres), ptr(g_rotres), ptr(g_scaleres), stream_ptr(dev)),
+                "mvp_prim_residuals_backward")
+        return (g_pos0, g_rot0, None, g_posres if need[3] else None, g_rotres if need[4] else None,
+                g_scaleres if need[5] else None, None, None, None)
+
+
+def prim_residuals(pos0, rot0, scale0, posres, rotres, scaleres, residuals_weight, nframes):
+    """The reference's residual composition (assembler.py:241-253) as one kernel each way:
+        rw = clamp(residuals_weight, 0, 1); if rw < 1: posres *= rw; rotres *= rw; scaleres = scaleres * rw + (1 - rw)
+        primpos = pos0 + posres;  primrot = rot0 @ rodrigues(rotres);  primscale = scale0 * scaleres
+    pos0 / posres / rotres / scaleres: [N, K, 3] or [K, 3] (shared by the frames); rot0: [N, K, 3, 3] or [K, 3, 3]; scale0: a
+    tensor that broadcasts to [N, K, 3] (no gradient: a buffer in the reference).  Returns primpos [N, K, 3], primrot
+    [N, K, 3, 3], primscale [N, K, 3]."""
+    K = posres.shape[-2]
+    rw = min(max(float(residuals_weight), 0.0), 1.0)   # sorted([0, w, 1])[1]
+    return _PrimResiduals.apply(pos0, rot0, scale0, posres, rotres, scaleres, rw, int(nframes), int(K))

@@ -84,8 +84,13 @@ def rodrigues_matrix(rvec: torch.Tensor) -> torch.Tensor:
     a = rvec / theta
     c, sn = torch.cos(theta)[..., None], torch.sin(theta)[..., None]          # [...,1,1]
     eye = torch.eye(3, dtype=rvec.dtype, device=rvec.device)
-    skew = torch.matmul(a, _SKEW.to(device=rvec.device, dtype=rvec.dtype).reshape(3, 9)).reshape(rvec.shape[:-1] + (3, 3))
+    skew = (a[..., :, None, None] * _SKEW.to(device=rvec.device, dtype=rvec.dtype)).sum(-3)   # sum_c a_c * _SKEW[c]
     return c * eye + (1.0 - c) * (a[..., :, None] * a[..., None, :]) + sn * skew
+
+
+def _matmul3(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b for stacks of 3x3 matrices, written as a broadcast product and a sum (no batched-GEMM launch)."""
+    return (a[..., :, :, None] * b[..., None, :, :]).sum(-2)
 
 
 def assemble_template_eager(tex, opacity, nboxes, boxsize):
@@ -116,6 +121,31 @@ class _FrameGain(torch.autograd.Function):
         base, gain = ctx.saved_tensors
         g2 = g.reshape(g.shape[0], -1)
         return torch.mv(g2.t(), gain).view_as(base), torch.mv(g2, base.reshape(-1))
+
+
+class _WideLinear(torch.autograd.Function):
+    """y = x W^T + b for a few rows x [B, C] and a very wide W [M, C] (the geometry head: B = 4, C = 16, M = 49152).  The
+    input gradient g W reduces over M with a 4 x 16 output; hipBLASLt's pick for that shape takes 112 us at C3
+    (profiles/r04z_train_C3_kernel_stats.csv, MT16x16x512; a broadcast product + reduction over a [B, M, C] temporary: 80 us)
+    against ~15 for the same product split over M by hand (a batched GEMM with K = 1024 and a 48-term sum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = None
+        if ctx.needs_input_grad[0]:
+            M = weight.shape[0]
+            if M % 1024 == 0 and M > 1024:   # split-K by hand: [S, B, 1024] x [S, 1024, C] -> sum over S
+                S = M // 1024
+                gx = torch.bmm(g.view(g.shape[0], S, 1024).transpose(0, 1), weight.view(S, 1024, -1)).sum(0)
+            else:
+                gx = g @ weight
+        return gx, g.t() @ x, g.sum(0)
 
 
 class CodeEncoderStandIn(nn.Module):
@@ -232,22 +262,28 @@ class SlabDecoderStandIn(nn.Module):
         gain = 1.0 + 0.1 * torch.tanh(self.gain(code))                      # [B,1] or [B,K]
         if self.conv_layout:
             if self.tex.is_cuda and self.tex.dtype == torch.float32:
-                from .assemble import assemble_template
-                base = assemble_template(self.tex, self.opacity, self.K, self.slab)          # [1,K,s,s,s,4], one kernel
+                # one pass each way: slabs made and scaled per frame in the hand-off kernel; its backward reads the
+                # incoming gradient once (it was: assemble + broadcast multiply, two gemv + the assemble backward)
+                from .assemble import assemble_template_frames
+                template = assemble_template_frames(self.tex, self.opacity, gain[:, 0].contiguous(), self.K, self.slab)
             else:
                 base = assemble_template_eager(self.tex, self.opacity, self.K, self.slab)
-            template = _FrameGain.apply(base[0], gain[:, 0])                                # [B,K,s,s,s,4]
+                template = _FrameGain.apply(base[0], gain[:, 0])                            # [B,K,s,s,s,4]
         else:
             rgb = torch.relu(self.rgb * 25.0 + 100.0)                        # assembler.py:261
             alpha = torch.relu(self.alpha)
             template = torch.cat([rgb[None] * gain[:, :, None, None, None, None],
                                   alpha[None].expand(B, -1, -1, -1, -1, -1)], dim=-1).contiguous()
         pos_res, rot_res, scale_res = 0.01 * self.pos_delta, 0.1 * self.rotvec, torch.exp(0.1 * self.logscale)
-        if rw < 1.0:                                                          # assembler.py:242-245
+        # On the GPU the residual composition (assembler.py:241-253) is one kernel each way (placement.prim_residuals, SURVEY 8f
+        # row N2) instead of ~25 small kernels forward and ~60 backward; on CPU the reference's statements.
+        fused_pose = self.pos_delta.is_cuda and self.pos_delta.dtype == torch.float32
+        if rw < 1.0 and not fused_pose:                                       # assembler.py:242-245
             pos_res, rot_res, scale_res = pos_res * rw, rot_res * rw, scale_res * rw + (1.0 - rw)
         out = {}
         if self.geometry:
-            geo = self.geo_head(code).view(B, self.K, 3) * self.vertstd + self.vertmean      # assembler.py:100-103
+            geo = _WideLinear.apply(code, self.geo_head.weight, self.geo_head.bias).view(B, self.K, 3) * self.vertstd \
+                + self.vertmean                                                              # assembler.py:100-103
             out["verts"] = geo
             guide = geo
             if gt_geo is not None and sch.get("use_gt_geo", False):
@@ -259,12 +295,23 @@ class SlabDecoderStandIn(nn.Module):
                 pm = (self.tri_bar[None, :, :, None] * guide[:, self.tri_idx]).sum(dim=2) / self.volradius
             with torch.no_grad():
                 aw = self._update_adaptwarps(pm, bool(sch.get("running_avg_scale", False)))
+            pos0, scale0 = pm, (aw * 0.8)[:, None]
+        else:
+            pos0, scale0 = self.base_pos, self.base_scale
+        if fused_pose:
+            from .placement import prim_residuals
+            primpos, primrot, primscale = prim_residuals(pos0, self.base_rot, scale0, pos_res, rot_res, scale_res, rw, B)
+            out.update(template=template, primpos=primpos, primrot=primrot, primscale=primscale)
+            return out
+        if self.geometry:
             primpos = (pm + pos_res[None]).contiguous()
             primscale = ((aw * 0.8)[None, :, None] * scale_res[None]).expand(B, -1, -1).contiguous()
         else:
             primpos = (self.base_pos + pos_res)[None].expand(B, -1, -1).contiguous()
             primscale = (self.base_scale * scale_res)[None].expand(B, -1, -1).contiguous()
-        primrot = torch.matmul(self.base_rot, rodrigues_matrix(rot_res))[None].expand(B, -1, -1, -1).contiguous()
+        # base_rot @ R as a broadcast product + sum: hipBLASLt's batched GEMM takes 150 us for 16384 3x3 products (and twice
+        # that in the backward); two elementwise kernels take ~10 (profiles/r04z_train_C3_kernel_stats.csv)
+        primrot = _matmul3(self.base_rot, rodrigues_matrix(rot_res))[None].expand(B, -1, -1, -1).contiguous()
         out.update(template=template, primpos=primpos, primrot=primrot, primscale=primscale)
         return out
 
@@ -469,7 +516,12 @@ class Trainer:
 
     def __init__(self, model: nn.Module, lr: float = 2.0e-4, lr_scheduler_iter: int = 10_000, gamma: float = 1.4,
                  clip: float = 1.0, loss_weights: Optional[Dict[str, float]] = None, ddp: bool = False,
-                 device_ids=None, bucket_cap_mb: int = 256):
+                 device_ids=None, bucket_cap_mb: int = 256, graph: bool = False, graph_warmup: int = 3):
+        """`graph=True` (single process, GPU): after `graph_warmup` eager iterations of a forward schedule the whole
+        iteration -- forward, losses, backward, gradient hygiene, Adam -- is captured once into a hipGraph and replayed: one
+        launch per iteration instead of ~350 (the stand-in's small tensors make the eager loop host-bound at C3).  A change of
+        the forward schedule (ddp-train.py:371-377, at iteration 100) captures a second graph; the learning-rate schedule
+        writes a device scalar the captured Adam reads."""
         self.raw_model = model
         if ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
@@ -479,12 +531,20 @@ class Trainer:
                         bucket_cap_mb=bucket_cap_mb)
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
+        on_gpu = bool(self.params) and self.params[0].is_cuda
+        self.graph = bool(graph) and on_gpu and not ddp
         # (the reference's torch.optim.Adam, ddp-train.py:78; on the GPU as ONE multi-tensor kernel instead of the ~10
-        #  foreach passes over every parameter -- the same update)
-        self.optim = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999),
-                                      fused=bool(self.params) and self.params[0].is_cuda)
+        #  foreach passes over every parameter -- the same update; for graph replay with the step count and the learning
+        #  rate on the device)
+        self._lr0, self._lr_iter, self._gamma = float(lr), int(lr_scheduler_iter), float(gamma)
+        if self.graph:
+            self._lr_dev = torch.tensor(float(lr), device=self.params[0].device, dtype=torch.float32)
+            self.optim = torch.optim.Adam(self.params, lr=self._lr_dev, betas=(0.9, 0.999), fused=True, capturable=True)
+            self.sched = None
+        else:
+            self.optim = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), fused=on_gpu)
+            self.sched = torch.optim.lr_scheduler.StepLR(self.optim, step_size=lr_scheduler_iter, gamma=gamma)
         self.ddp = ddp
-        self.sched = torch.optim.lr_scheduler.StepLR(self.optim, step_size=lr_scheduler_iter, gamma=gamma)
         self.clip = clip
         self.loss_weights = dict(loss_weights or REFERENCE_LOSS_WEIGHTS)  # configs/config.yaml:17-21
         self.iternum = 0
@@ -492,6 +552,8 @@ class Trainer:
         self._model_takes_target = "target" in inspect.signature(self.raw_model.forward).parameters
         self._clipper = None
         self.last_grad_norm = None
+        self._graphs, self._eager_seen, self._graph_warmup = {}, {}, int(graph_warmup)
+        self.graph_replays = 0
 
     @classmethod
     def from_config(cls, model, cfg, **kw):
@@ -514,7 +576,11 @@ class Trainer:
             dec = self.raw_model.decoder
             out["vertl1"] = mean_ell_1(output["verts"], batch["verts"] * dec.vertstd + dec.vertmean)
         if "primvolsum" in self.loss_weights:
-            out["primvolsum"] = torch.sum(torch.prod(1.0 / output["primscale"], dim=-1), dim=-1)
+            # ddp-train.py:415 `torch.sum(torch.prod(1 / primscale, dim=-1), dim=-1)` with the three-factor product written out:
+            # the backward of torch.prod(dim) counts zeros with `.item()` -- a host synchronisation per iteration, and the
+            # one statement of the iteration a hipGraph capture refuses.  Same values.
+            inv = 1.0 / output["primscale"]
+            out["primvolsum"] = torch.sum(inv[..., 0] * inv[..., 1] * inv[..., 2], dim=-1)
         if "kldiv" in self.loss_weights and output.get("expr_mu") is not None:
             out["kldiv"] = kl_loss_stable(output["expr_mu"], output["expr_logstd"])
         if not out:
@@ -525,9 +591,10 @@ class Trainer:
         """ddp-train.py:424-430 (no (value, weight) tuples on this path: every term is a plain mean)."""
         return sum(self.loss_weights[k] * torch.mean(v) for k, v in losses.items())
 
-    def step(self, batch: Dict[str, torch.Tensor]):
+    def _iteration(self, batch, schedule):
+        """Forward, losses, backward, gradient hygiene, optimiser -- everything of ddp-train.py:371-442 that runs on the device."""
         output = self.model(batch["camrot"], batch["campos"], batch["focal"], batch["princpt"], batch["pixelcoords"],
-                            batch["code"], schedule=forward_schedule(self.iternum), camindex=batch.get("camindex"),
+                            batch["code"], schedule=schedule, camindex=batch.get("camindex"),
                             idindex=batch.get("idindex"), gt_verts=batch.get("verts"), noise=batch.get("noise"),
                             **({"target": batch["image"]} if self._model_takes_target and "irgbl1" in self.loss_weights else {}))
         losses = self.losses(output, batch)
@@ -552,9 +619,57 @@ class Trainer:
                     p.grad.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.params, self.clip)
         self.optim.step()
-        self.sched.step()
-        self.iternum += 1
         return loss.detach(), {k: v.detach().mean() for k, v in losses.items()}
+
+    def _advance(self):
+        if self.sched is not None:
+            self.sched.step()
+        self.iternum += 1
+        if self.sched is None:  # StepLR by hand (ddp-train.py:82): the captured Adam reads this device scalar
+            lr = self._lr0 * self._gamma ** (self.iternum // self._lr_iter)
+            if self.iternum % self._lr_iter == 0:
+                self._lr_dev.fill_(lr)
+
+    def step(self, batch: Dict[str, torch.Tensor]):
+        schedule = forward_schedule(self.iternum)
+        if not self.graph:
+            out = self._iteration(batch, schedule)
+            self._advance()
+            return out
+        key = tuple(sorted(schedule.items()))
+        st = self._graphs.get(key)
+        if st is None:
+            seen = self._eager_seen.get(key, 0)
+            if seen < self._graph_warmup:      # lazy initialisation (Adam state, list capacities, index checks) happens here
+                self._eager_seen[key] = seen + 1
+                out = self._iteration(batch, schedule)
+                self._advance()
+                return out
+            st = self._graphs[key] = self._capture(batch, schedule)
+        for k, t in st["in"].items():
+            src = batch[k]
+            if src.data_ptr() != t.data_ptr():
+                t.copy_(src)
+        st["graph"].replay()
+        self.graph_replays += 1
+        self.last_grad_norm = st["norm"]
+        self._advance()
+        return st["loss"], st["parts"]
+
+    def _capture(self, batch, schedule):
+        """One iteration recorded into a hipGraph (torch.cuda.CUDAGraph): inputs are copied into tensors the graph owns, every
+        intermediate -- gradients included -- lives in the graph's private pool and is reused by each replay.  The operators
+        of this package skip their host-side bookkeeping while a stream is being captured (list-capacity feedback, index
+        checks), so the capacities of this moment are the graph's."""
+        static_in = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        torch.cuda.synchronize()
+        self.optim.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, parts = self._iteration(static_in, schedule)
+            norm = self.last_grad_norm
+        # the capture itself ran nothing: the first replay is this iteration
+        return {"graph": g, "in": static_in, "loss": loss, "parts": parts, "norm": norm}
 
 
 @torch.no_grad()

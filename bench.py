@@ -231,7 +231,7 @@ def kernel_averages(events):
     return {k: sum(v) / len(v) for k, v in kt.items()}
 
 
-def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None, config=None):
+def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None, config=None, graph=False):
     """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object.  `config` =
     config.load_train_config(...) of one of the reference's YAML files: its batch size per GPU and hyper-parameters."""
     from ava256_amd import _hooks as mm
@@ -249,9 +249,9 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
     nparams = sum(p.numel() for p in model.parameters())
     ddp = (world > 1) if ddp is None else ddp
     if config is not None:
-        tr = Trainer.from_config(model, config, ddp=ddp, device_ids=[local_rank] if ddp else None)
+        tr = Trainer.from_config(model, config, ddp=ddp, device_ids=[local_rank] if ddp else None, graph=graph)
     else:
-        tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None)
+        tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None, graph=graph)
     state = {}
 
     def step():
@@ -268,7 +268,9 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
            "ms_per_iter": 1e3 * elapsed / steps, "steps": steps, "frames_per_s": N * world * steps / elapsed,
            "allreduce_mb": nparams * 4e-6 if ddp else 0.0, "param_mb": nparams * 4e-6,
            "kernel_ms": kernel_averages(events), "final_loss": float(state["loss"]),
-           "hyper_parameters": {"lr": tr.optim.param_groups[0]["initial_lr"], "clip": tr.clip,
+           "launch": ("one hipGraph replay per iteration (Trainer(graph=True): %d of the %d timed iterations)"
+                      % (min(tr.graph_replays, steps), steps)) if tr.graph else "eager (one launch per kernel)",
+           "hyper_parameters": {"lr": tr._lr0, "clip": tr.clip,
                                 "loss_weights": tr.loss_weights, "from": "config file" if config else "configs/config.yaml values"},
            "background_mlp": ("fused MFMA kernels (csrc/bgmlp.hip: bf16 operands, fp32 accumulation), %.1f GFLOP fwd per "
                               "iteration" % (px * 2 * (120 * 256 + 4 * 256 * 256 + 256 * 3) * 1e-9))
@@ -483,8 +485,18 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         # training path with a stand-in decoder.  C3 = the reference's per-GPU batch shape (4 frames, K=16384) with the
         # background MLP (fused MFMA kernels); C2 = the 80-frame render batch, background off and (C2_bg) on.
         train = {"note": "stand-in decoder (per-primitive slab parameters), NOT ava-256's conv stacks",
-                 "C3": train_leg("C3", 8, 2, rank, local_rank, world, dev, dist, with_bg=True),
-                 "C2": train_leg("C2", 6, 2, rank, local_rank, world, dev, dist, with_bg=False)}
+                 "C3": train_leg("C3", 16, 5, rank, local_rank, world, dev, dist, with_bg=True),
+                 "C2": train_leg("C2", 10, 5, rank, local_rank, world, dev, dist, with_bg=False)}
+        if world == 1:
+            # single process: the same iterations as ONE hipGraph replay each (Trainer(graph=True)); the eager rows above keep
+            # the per-kernel HIP-event averages, which a replay cannot record
+            for key, (st, wu, bg) in (("C3", (16, 7, True)), ("C2", (10, 7, False))):
+                try:
+                    g = train_leg(key, st, wu, rank, local_rank, world, dev, dist, with_bg=bg, graph=True)
+                    train[key]["graph"] = {k: g[k] for k in ("iters_per_s", "ms_per_iter", "frames_per_s", "steps", "launch",
+                                                             "final_loss")}
+                except Exception as e:  # a capture that fails must not cost the bench line
+                    train[key]["graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # the 80-frame batch WITH the background MLP: its bf16 activations and their gradients for the backward are
         # 2 x 54 GB (80 x 512 x 512 pixels x 5 layers x 256 channels) -- run when the device has the room
         # (the decision is taken by ALL ranks together -- a rank that skipped the leg would leave the others in its barrier)

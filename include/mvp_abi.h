@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 12
+#define MVP_ABI_VERSION 13
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -170,6 +170,39 @@ int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const 
                                   void *stream);
 int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
                                    float *grad_tex, float *grad_opacity, void *stream);
+/* Frame-broadcast form of the same hand-off: ONE decoder output (tex [1,3*B,S,S], opacity [1,B,S,S]) shared by F frames,
+ * frame f scaled by gain[f] in all four channels:  tplate [F, nh*nh, B,B,B, 4] = gain[f] * assemble(tex, opacity).
+ * (User: the stand-in decoder of the train leg, ava-256_amd/trainloop.py; the reference's decoders emit per-frame outputs
+ * and use the form above.)  Backward reads grad_tplate once: grad_tex / grad_opacity fully written (gradient of the shared
+ * output = sum_f gain[f] * grad_tplate[f] through the relu), gain_partials [blocks, F] = per-workgroup partial sums of
+ * <grad_tplate[f], base> -- the caller sums over blocks (blocks = mvp_template_assemble_frames_blocks(nh, B)); F <= 1024. */
+long long mvp_template_assemble_frames_blocks(int nh, int B);
+int mvp_template_assemble_frames_forward(int F, int nh, int B, const float *tex, const float *opacity, const float *gain,
+                                         float *tplate, void *stream);
+int mvp_template_assemble_frames_backward(int F, int nh, int B, const float *tex, const float *opacity, const float *gain,
+                                          const float *grad_tplate, float *grad_tex, float *grad_opacity,
+                                          float *gain_partials, void *stream);
+
+/* Residual half of the hand-off (models/decoders/assembler.py:241-253, eager in the reference; `rodrig` = models/utils.py
+ * Rodrigues): rw = clamp(residuals_weight, 0, 1);  if rw < 1: posres *= rw, rotres *= rw, scaleres = scaleres*rw + (1-rw);
+ *   primpos = pos0 + posres;   primrot = pos-wise bmm(rot0, rodrig(rotres));   primscale = scale0 * scaleres.
+ * pos0 / posres / rotres (axis-angle) / scaleres: [N or 1, K, 3]; rot0: [N or 1, K, 3, 3]; *_sn = frame stride in floats
+ * (K*3 resp. K*9, or 0 = one array shared by the N frames); scale0: any broadcast of [N, K, 3] given by its three strides
+ * (a scalar: 0,0,0; adaptwarps*0.8 [K]: 0,1,0).  Outputs [N,K,3], [N,K,3,3], [N,K,3], fully written; rw in [0, 1].
+ * Backward: gradients shaped like their inputs, fully written (a shared input's gradient is the sum over the frames);
+ * grad_pos0 / grad_rot0 may be NULL (not needed); scale0 gets none (a buffer in the reference: assembler.py:66,183-199). */
+int mvp_prim_residuals_forward(int N, int K, float rw, const float *pos0, long long pos0_sn, const float *rot0,
+                               long long rot0_sn, const float *scale0, long long scale0_sn, long long scale0_sk,
+                               long long scale0_sc, const float *posres, long long posres_sn, const float *rotres,
+                               long long rotres_sn, const float *scaleres, long long scaleres_sn, float *primpos,
+                               float *primrot, float *primscale, void *stream);
+int mvp_prim_residuals_backward(int N, int K, float rw, const float *pos0, long long pos0_sn, const float *rot0,
+                                long long rot0_sn, const float *scale0, long long scale0_sn, long long scale0_sk,
+                                long long scale0_sc, const float *posres, long long posres_sn, const float *rotres,
+                                long long rotres_sn, const float *scaleres, long long scaleres_sn,
+                                const float *grad_primpos, const float *grad_primrot, const float *grad_primscale,
+                                float *grad_pos0 /*or NULL*/, float *grad_rot0 /*or NULL*/, float *grad_posres,
+                                float *grad_rotres, float *grad_scaleres, void *stream);
 
 /* NHWC -> NCHW split of the march result.  Replaces `rayrgba.permute(0,3,1,2)` + `[:, :3].contiguous()` +
  * `[:, 3:4].contiguous()` of /root/reference/models/raymarchers/mvpraymarcher.py:50-51 (and autograd's slice / copy

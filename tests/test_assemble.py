@@ -63,3 +63,32 @@ def test_kernel_bit_exact_and_backward(cfg):
     assert torch.equal(eager, out.detach())
     eager.backward(gout)
     assert torch.equal(t2.grad, tex.grad) and torch.equal(o2.grad, op.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(3, 3, 4), (5, 16, 8), (4, 128, 8), (0, 3, 4)], ids=lambda c: "F%d_nh%d_B%d" % c)
+def test_frame_broadcast_form_equals_assemble_times_gain(cfg):
+    """mvp_template_assemble_frames_*: tplate[f] = gain[f] * assemble(tex, opacity) in one pass each way.  Forward bit-equal
+    to the eager product (one rounding per element either way); backward against autograd of the eager statements
+    (sums over frames / voxels in a different order: 1e-5 of the largest magnitude)."""
+    from ava256_amd.assemble import assemble_template, assemble_template_frames
+    F, nh, B = cfg
+    S = nh * B
+    g = torch.Generator(device="cuda").manual_seed(11)
+    tex = (torch.randn(1, 3 * B, S, S, device="cuda", generator=g) * 2.0 - 3.5).requires_grad_(True)
+    op = torch.randn(1, B, S, S, device="cuda", generator=g).requires_grad_(True)
+    gain = (1.0 + 0.3 * torch.randn(F, device="cuda", generator=g)).requires_grad_(True)
+    out = assemble_template_frames(tex, op, gain, nh * nh, B)
+    assert out.shape == (F, nh * nh, B, B, B, 4)
+    t2, o2, g2 = (t.detach().clone().requires_grad_(True) for t in (tex, op, gain))
+    eager = g2.view(-1, 1, 1, 1, 1, 1) * assemble_template(t2, o2, nh * nh, B)
+    assert torch.equal(out.detach(), eager.detach())
+    gout = torch.randn(out.shape, device="cuda", generator=g)
+    out.backward(gout)
+    eager.backward(gout)
+    for a, b in ((tex.grad, t2.grad), (op.grad, o2.grad), (gain.grad, g2.grad)):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        if F == 0:
+            assert not a.any()
+        else:
+            assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())

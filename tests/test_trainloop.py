@@ -321,3 +321,59 @@ def test_matrix_form_of_rodrigues_equals_the_per_element_form():
     assert R.shape == (203, 3, 3) and torch.isfinite(R).all()
     R.sum().backward()
     assert torch.isfinite(v32.grad).all()
+
+
+def test_gemm_free_small_products_equal_the_matrix_products():
+    """trainloop._matmul3 (stacks of 3x3 products as a broadcast product + sum) and trainloop._WideLinear (the geometry head
+    with its input gradient as a broadcast product + sum) give what torch.matmul / F.linear give, gradients included."""
+    from ava256_amd.trainloop import _matmul3, _WideLinear
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(50, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(50, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(50, 3, 3, generator=g, dtype=torch.float64)
+    ga, gb = torch.autograd.grad((_matmul3(a, b) * w).sum(), (a, b))
+    ra, rb = torch.autograd.grad((torch.matmul(a, b) * w).sum(), (a, b))
+    assert (_matmul3(a, b) - torch.matmul(a, b)).abs().max().item() <= 1e-14
+    assert (ga - ra).abs().max().item() <= 1e-13 and (gb - rb).abs().max().item() <= 1e-13
+    for M in (300, 3072):        # plain product, and the split-over-M form (M a multiple of 1024)
+        x = torch.randn(4, 16, generator=g, dtype=torch.float64, requires_grad=True)
+        W = torch.randn(M, 16, generator=g, dtype=torch.float64, requires_grad=True)
+        bias = torch.randn(M, generator=g, dtype=torch.float64, requires_grad=True)
+        u = torch.randn(4, M, generator=g, dtype=torch.float64)
+        got = torch.autograd.grad((_WideLinear.apply(x, W, bias) * u).sum(), (x, W, bias))
+        ref = torch.autograd.grad((torch.nn.functional.linear(x, W, bias) * u).sum(), (x, W, bias))
+        assert (_WideLinear.apply(x, W, bias) - torch.nn.functional.linear(x, W, bias)).abs().max().item() <= 1e-13
+        for p_, q_ in zip(got, ref):
+            assert (p_ - q_).abs().max().item() <= 1e-11
+
+@pytest.mark.gpu
+def test_graph_replay_trains_like_the_eager_loop():
+    """Trainer(graph=True): after the eager warm-up iterations of a forward schedule the iteration is one hipGraph replay.
+    Same initialisation, same batch, 12 iterations across ... the losses and the parameters follow the eager loop's (the
+    placement backward accumulates with fp32 atomics, so not bit for bit: 1e-4 relative on the loss, 1e-3 of the largest
+    update on the parameters), the learning-rate scalar the captured Adam reads is the schedule's, and replays happened."""
+    from ava256_amd.trainloop import (CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel, SlabDecoderStandIn, Trainer,
+                                      make_training_batch)
+    dev = "cuda"
+    batch, volradius = make_training_batch(2, 64, 64, 256, dev, seed=5, target_decoder=SlabDecoderStandIn(256, seed=9))
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = RaymarchTrainModel(SlabDecoderStandIn(256, seed=1), volradius, colorcal=ColorCalStandIn(80, 4),
+                                   encoder=CodeEncoderStandIn()).to(dev)
+        tr = Trainer(model, lr=1e-3, lr_scheduler_iter=5, gamma=0.5, graph=graph, graph_warmup=2)
+        losses = []
+        for _ in range(12):
+            loss, parts = tr.step(batch)
+            losses.append(float(loss))
+        return tr, losses, [p.detach().clone() for p in tr.params]
+
+    te, le, pe = run(False)
+    tg, lg, pg = run(True)
+    assert tg.graph and tg.graph_replays == 10 and te.graph_replays == 0
+    assert abs(float(tg._lr_dev) - 1e-3 * 0.25) <= 1e-9 and abs(te.optim.param_groups[0]["lr"] - 1e-3 * 0.25) <= 1e-12
+    for a, b in zip(le, lg):
+        assert np.isfinite(b) and abs(a - b) <= 1e-4 * abs(a), (le, lg)
+    for a, b in zip(pe, pg):
+        assert (a - b).abs().max().item() <= 1e-3 * 12 * 1e-3 + 1e-6 * a.abs().max().item()
+    assert torch.isfinite(tg.last_grad_norm).all()

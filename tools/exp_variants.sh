@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p build_variants
 for n in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -fno-slp-vectorize -fno-gpu-rdc -Wno-unused-function \
-    -DMVP_EXP=$n -I include -I ava-256_amd/csrc ava-256_amd/csrc/{raydirs,aabb,march,assemble,placement,gradclip,bgmlp,pixeltail,abi_misc}.hip \
+    -DMVP_EXP=$n -I include -I ava-256_amd/csrc ava-256_amd/csrc/{raydirs,aabb,march,assemble,placement,gradclip,bgmlp,pixeltail,primpose,abi_misc}.hip \
     -o build_variants/libmvp_exp$n.so &
 done
 wait

@@ -5,7 +5,7 @@ set -eu
 cd "$(dirname "$0")/.."
 TMP=$(mktemp -d)
 echo "source,kernel,vgpr,vgpr_spill,sgpr,sgpr_spill,lds_bytes,scratch_bytes,waves_per_simd_by_vgpr" > profiles/kernel_resources.csv
-for f in raydirs aabb march assemble placement gradclip bgmlp pixeltail abi_misc; do
+for f in raydirs aabb march assemble placement gradclip bgmlp pixeltail primpose abi_misc; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -I include -I ava-256_amd/csrc -S --cuda-device-only \
         ava-256_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
   python3 - "$TMP/$f.s" "$f" >> profiles/kernel_resources.csv <<'PY'
