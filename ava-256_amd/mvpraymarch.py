@@ -73,7 +73,7 @@ def primlist_capacity(H, W, K, device=None, N=None):
     cap = (int(min(max(32.0, 4 * 10.0 * packets / max(K, 1)), 2048)) + 7) // 8 * 8
     st = _LIST_DEMAND.get((getattr(device, "index", None), H, W, K)) if device is not None else None
     if st is not None:
-        if not torch.cuda.is_current_stream_capturing():   # (an event query is not a capturable call)
+        if st.event is not None and not torch.cuda.is_current_stream_capturing():   # (an event query cannot be captured)
             st.poll()
         if st.demand > 0:
             cap = (int(min(max(32.0, 1.25 * st.demand), 2048)) + 7) // 8 * 8
