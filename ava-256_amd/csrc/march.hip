@@ -1686,7 +1686,8 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
 // Timing experiments of the primitive-centric backward (tools/exp_variants.sh builds them, never the product library):
 //   1 = conflict-free scatter addresses, 2 = no scatter atomics, 3 = no march at all (front-end chain: staging, phase 1,
 //   queue, phase-2 ray loads, output) -- all compute WRONG gradients: time only,
-//   4 = count same-address / same-bank lanes per 32-lane group into diag (tools/exp4_stats.py).
+//   4 = count same-address / same-bank lanes per 32-lane group into diag (tools/exp4_stats.py),
+//   6 = fp32 LDS atomics in the scatter instead of conversion + integer atomics (WRONG gradients: time only).
 #define MVP_EXP 0
 #endif
 // Waves per workgroup (one workgroup = one primitive) is a template parameter of the kernel, PW in {2, 3}.  The kernel is
@@ -2491,7 +2492,15 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
 #define MVP_FIX1(OFF_, VAL_) exp_sink ^= fix_rn(VAL_) + (int)(OFF_);
 #define MVP_FIX1B(OFF_, VAL_) MVP_FIX1(OFF_, VAL_)
 #else
+#if MVP_EXP == 6
+// timing build: fp32 LDS atomics (ds_add_f32), no conversion -- the flush still reads integers: WRONG gradients, time only
+#define MVP_FIX1(OFF_, VAL_) __hip_atomic_fetch_add(reinterpret_cast<float *>(Ap) + (OFF_), (VAL_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif MVP_EXP == 7
+// timing build: integer atomics on the raw float bits (no conversion, no float atomic): WRONG gradients, time only
+#define MVP_FIX1(OFF_, VAL_) atomicAdd(Ap + (OFF_), __float_as_int(VAL_));
+#else
 #define MVP_FIX1(OFF_, VAL_) atomicAdd(Ap + (OFF_), fix_rn(VAL_));
+#endif
 // pass B of a two-pass round: what pass A rounded away, x - rn(x) (exact in fp32), at res_mul units per unit
 #define MVP_FIX1B(OFF_, VAL_)                                                   \
     {                                                                           \
