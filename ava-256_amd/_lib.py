@@ -47,6 +47,8 @@ _POSE_IN = [_c_int, _c_int, ctypes.c_float, _c_void_p, ctypes.c_longlong, _c_voi
             ctypes.c_longlong, _c_void_p, ctypes.c_longlong]
 SIGNATURES["mvp_prim_residuals_forward"] = (_c_int, _POSE_IN + [_c_void_p] * 4)
 SIGNATURES["mvp_prim_residuals_backward"] = (_c_int, _POSE_IN + [_c_void_p] * 9)
+SIGNATURES["mvp_prim_frame_forward"] = (_c_int, [ctypes.c_longlong] + [_c_void_p] * 4)
+SIGNATURES["mvp_prim_frame_backward"] = (_c_int, [ctypes.c_longlong] + [_c_void_p] * 6)
 # N,H,W | rayrgba | rayrgb,rayalpha | stream     and     N,H,W | g_rgb,g_alpha | g_rgba | stream
 SIGNATURES["mvp_rgba_split_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_void_p])
 SIGNATURES["mvp_rgba_split_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 3 + [_c_void_p])
@@ -71,7 +73,7 @@ SIGNATURES["mvp_pixel_tail_blocks"] = (_c_int, [_c_int] * 2)
 SIGNATURES["mvp_pixel_tail_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 8 + [_c_void_p])
 # N,H,W | rayrgba,cw,bg,target,irgbrec,g_irgbrec,g_ialpha,g_l1 | grad_rayrgba,grad_bg,cwcb_partials | stream
 SIGNATURES["mvp_pixel_tail_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 11 + [_c_void_p])
-ABI_VERSION = 13
+ABI_VERSION = 14
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -179,3 +179,35 @@ def prim_residuals(pos0, rot0, scale0, posres, rotres, scaleres, residuals_weigh
     K = posres.shape[-2]
     rw = min(max(float(residuals_weight), 0.0), 1.0)   # sorted([0, w, 1])[1]
     return _PrimResiduals.apply(pos0, rot0, scale0, posres, rotres, scaleres, rw, int(nframes), int(K))
+
+
+class _PrimFrame(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, du, dv):
+        du, dv = require_device_f32("vcenterdu", du.contiguous()), require_device_f32("vcenterdv", dv.contiguous())
+        if du.shape != dv.shape or du.shape[-1] != 3:
+            raise RuntimeError("vcenterdu / vcenterdv must have equal shapes [..., 3]")
+        M = du.numel() // 3
+        rot = torch.empty(du.shape[:-1] + (3, 3), device=du.device, dtype=torch.float32)
+        with torch.cuda.device(du.device):
+            _lib.check(_lib.get_lib().mvp_prim_frame_forward(M, ptr(du), ptr(dv), ptr(rot), stream_ptr(du.device)),
+                       "mvp_prim_frame_forward")
+        ctx.save_for_backward(du, dv)
+        return rot
+
+    @staticmethod
+    def backward(ctx, g):
+        du, dv = ctx.saved_tensors
+        g = g.contiguous().float()
+        gdu, gdv = torch.empty_like(du), torch.empty_like(dv)
+        with torch.cuda.device(du.device):
+            _lib.check(_lib.get_lib().mvp_prim_frame_backward(du.numel() // 3, ptr(du), ptr(dv), ptr(g), ptr(gdu), ptr(gdv),
+                                                              stream_ptr(du.device)), "mvp_prim_frame_backward")
+        return gdu, gdv
+
+
+def prim_frame(vcenterdu, vcenterdv):
+    """The TBN matrix of assembler.py:226-239 as one kernel each way: vcenterdu / vcenterdv [B, ny, nx, 3] (prim_placement's
+    outputs) -> primrot [B, ny*nx, 3, 3] with columns tangent, bitangent, normal."""
+    rot = _PrimFrame.apply(vcenterdu, vcenterdv)
+    return rot.reshape(rot.shape[0], -1, 3, 3) if rot.dim() > 3 else rot

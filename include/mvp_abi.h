@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 13
+#define MVP_ABI_VERSION 14
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -203,6 +203,14 @@ int mvp_prim_residuals_backward(int N, int K, float rw, const float *pos0, long 
                                 const float *grad_primpos, const float *grad_primrot, const float *grad_primscale,
                                 float *grad_pos0 /*or NULL*/, float *grad_rot0 /*or NULL*/, float *grad_posres,
                                 float *grad_rotres, float *grad_scaleres, void *stream);
+
+/* The TBN frame of the hand-off (models/decoders/assembler.py:226-239, eager in the reference): from the centre texel's
+ * differences vcenterdu / vcenterdv [M, 3] (M = frames x primitives; what mvp_prim_placement_forward returns) the base
+ * orientation primrot [M, 3, 3] whose COLUMNS are tangent = du/|du|, bitangent = unit(normal x tangent), normal =
+ * unit(tangent x dv), every norm clamped at 1e-8 like the reference's.  Backward: grad_du / grad_dv fully written. */
+int mvp_prim_frame_forward(long long M, const float *du, const float *dv, float *primrot, void *stream);
+int mvp_prim_frame_backward(long long M, const float *du, const float *dv, const float *grad_primrot, float *grad_du,
+                            float *grad_dv, void *stream);
 
 /* NHWC -> NCHW split of the march result.  Replaces `rayrgba.permute(0,3,1,2)` + `[:, :3].contiguous()` +
  * `[:, 3:4].contiguous()` of /root/reference/models/raymarchers/mvpraymarcher.py:50-51 (and autograd's slice / copy

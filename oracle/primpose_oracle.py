@@ -69,3 +69,35 @@ def prim_residuals_backward(pos0, rot0, scale0, posres, rotres, scaleres, residu
     sr_shape, pr_shape, rr_shape = scaleres.shape, posres.shape, rotres.shape
     return (_unbroadcast(g_pos, pos0.shape), _unbroadcast(g_rot0, rot0.shape), _unbroadcast(g_pos * m, pr_shape),
             _unbroadcast(g_v * m, rr_shape), _unbroadcast(g_scale * scale0 * m, sr_shape))
+
+
+# ---- the TBN frame (models/decoders/assembler.py:227-239) ------------------------------------------------------------
+def _unit(x):
+    m = np.maximum(np.sqrt((x * x).sum(-1, keepdims=True)), 1e-8)      # torch.norm(...).clamp(min=1e-8)
+    return x / m, m
+
+
+def _unit_bwd(y, m, g):
+    free = m > 1e-8
+    return np.where(free, (g - y * (y * g).sum(-1, keepdims=True)) / m, g / m)
+
+
+def prim_frame(du, dv):
+    """vcenterdu / vcenterdv [..., 3] -> primrot [..., 3, 3] with COLUMNS tangent, bitangent, normal."""
+    t, _ = _unit(du)                                                   # assembler.py:228-229
+    n, _ = _unit(np.cross(t, dv))                                      # assembler.py:230-231
+    b, _ = _unit(np.cross(n, t))                                       # assembler.py:232-233
+    return np.stack([t, b, n], -2).swapaxes(-1, -2)                    # assembler.py:234-240 (stack rows, permute)
+
+
+def prim_frame_backward(du, dv, g_rot):
+    t, mt = _unit(du)
+    n, mn = _unit(np.cross(t, dv))
+    b, mb = _unit(np.cross(n, t))
+    gt, gb, gn = g_rot[..., :, 0], g_rot[..., :, 1], g_rot[..., :, 2]
+    gb0 = _unit_bwd(b, mb, gb)
+    gn = gn + np.cross(t, gb0)
+    gt = gt + np.cross(gb0, n)
+    gn0 = _unit_bwd(n, mn, gn)
+    gt = gt + np.cross(dv, gn0)
+    return _unit_bwd(t, mt, gt), np.cross(gn0, t)

@@ -1,10 +1,13 @@
-"""tests/golden/gen_primpose.py -- golden vectors of the residual composition (models/decoders/assembler.py:241-253) made with
-the reference's OWN `Rodrigues` module (models/utils.py:470-494, imported from the mounted reference) and autograd; the
-five statements around it are assembler.py's.  float64 inputs rounded to float32 values (so that the fp32 kernel and the f64
-oracle start from the same numbers), per-frame and shared residuals, residuals_weight below and above 1.
+"""tests/golden/gen_primpose.py -- golden vectors of the residual composition made from the REFERENCE'S OWN LINES: the text of
+/root/reference/models/decoders/assembler.py is read at run time and the statements from `rw = sorted(...)` to `primscale =
+primscale * primitives_scale_residuals` (assembler.py:241-253) are executed as they stand, with a stand-in `self` whose
+`rodrig` is the reference's own `Rodrigues` module (models/utils.py:470-494, imported from the mounted reference); autograd
+gives the gradients.  Nothing of the reference is stored.  float64 inputs rounded to float32 values (so that the fp32 kernel
+and the f64 oracle start from the same numbers), per-frame and shared residuals, residuals_weight below, at and above 1.
 Run in the build container; writes tests/golden/primpose.npz."""
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -17,6 +20,11 @@ if __name__ == "__main__":
     sys.path.insert(0, REF)
     from models.utils import Rodrigues                                  # utils.py:470-494
     rodrig = Rodrigues()
+    src = open(os.path.join(REF, "models/decoders/assembler.py")).read().split("\n")
+    i0 = next(i for i, l in enumerate(src) if l.strip().startswith("rw = sorted([0.0, residuals_weight, 1.0])[1]"))
+    i1 = next(i for i in range(i0, len(src)) if src[i].strip() == "primscale = primscale * primitives_scale_residuals")
+    CODE = "\n".join(l[8:] for l in src[i0:i1 + 1])
+    assert i1 - i0 == 11, (i0, i1)
     g = torch.Generator().manual_seed(41)
     out = {}
     for tag, N, K, shared, rwt in (("a", 3, 37, False, 0.35), ("b", 5, 70, True, 1.0), ("c", 2, 64, True, 1.7), ("d", 1, 5, False, 0.0)):
@@ -31,15 +39,14 @@ if __name__ == "__main__":
         rotres = rnd(*fs, 3, scale=0.4)
         rotres[..., :2, :] = 0.0                                         # zero rotation: theta = sqrt(1e-5)
         rotres = rotres.requires_grad_(True)
-        rw = sorted([0.0, rwt, 1.0])[1]                                  # assembler.py:241
-        pr, rr, sr = posres, rotres, scaleres
-        if rw < 1.0:                                                     # assembler.py:242-245
-            pr, rr, sr = pr * rw, rr * rw, sr * rw + (1 - rw)
-        primpos = pos0 + pr                                              # assembler.py:247
-        rres = rodrig(rr.expand(N, K, 3).reshape(-1, 3)).view(N, K, 3, 3)                       # assembler.py:248
-        primrot = torch.bmm(rot0.expand(N, K, 3, 3).reshape(-1, 3, 3), rres.view(-1, 3, 3)).view(N, K, 3, 3)   # :249-251
-        primscale = scale0 * sr                                          # assembler.py:252
-        primscale = primscale.expand(N, K, 3)
+        env = {"torch": torch, "residuals_weight": rwt, "nprims": K, "self": types.SimpleNamespace(rodrig=rodrig),
+               "expr_encoding": types.SimpleNamespace(size=lambda i: N),
+               "primitives_position_residuals": posres.expand(N, K, 3).contiguous(),
+               "primitives_rotation_residuals": rotres.expand(N, K, 3).contiguous(),
+               "primitives_scale_residuals": scaleres.expand(N, K, 3).contiguous(), "primpos": pos0,
+               "primrot": rot0.expand(N, K, 3, 3).contiguous(), "primscale": scale0}
+        exec(CODE, env)                                                  # assembler.py:241-253, as they stand
+        primpos, primrot, primscale = env["primpos"], env["primrot"], env["primscale"].expand(N, K, 3)
         gp, gr, gs = rnd(N, K, 3), rnd(N, K, 3, 3), rnd(N, K, 3)
         ((gp * primpos).sum() + (gr * primrot).sum() + (gs * primscale).sum()).backward()
         for name, t in (("pos0", pos0), ("rot0", rot0), ("scale0", scale0), ("posres", posres), ("rotres", rotres),

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 13
+    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 14
     assert b"bad argument" in lib.mvp_error_string(-1)
     assert lib.mvp_error_string(0) == b"ok"
 

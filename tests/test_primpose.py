@@ -118,3 +118,85 @@ def test_bad_arguments_are_refused():
         prim_residuals(*{**ok, "posres": torch.zeros(K, 3, device=dev, dtype=torch.float64)}.values(), 1.0, N)
     with pytest.raises(RuntimeError):
         prim_residuals(*{**ok, "pos0": torch.zeros(N, K, 3)}.values(), 1.0, N)                     # CPU tensor: no CPU path
+
+
+# ---- the TBN frame (assembler.py:227-240) --------------------------------------------------------------------------------
+def _frame_case(tag):
+    g = np.load(os.path.join(GOLDEN, "primframe.npz"))
+    return {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + "_")}
+
+
+@pytest.mark.parametrize("tag", ("a", "b"))
+def test_frame_oracle_matches_the_reference_lines(tag):
+    """oracle/primpose_oracle.prim_frame against vectors made by executing assembler.py:227-240 as they stand
+    (tests/golden/gen_primframe.py); case b holds a zero tangent difference and a dv parallel to du (the 1e-8 clamps)."""
+    from oracle import primpose_oracle as po
+    c = _frame_case(tag)
+    B = c["du"].shape[0]
+    rot = po.prim_frame(c["du"], c["dv"]).reshape(B, -1, 3, 3)
+    # dv parallel to du (case b, texel (1, 1)): t x dv is rounding noise divided by the 1e-8 clamp -- whatever the cross
+    # product's rounding leaves, different in every implementation, the reference's included: finite, not compared
+    keep = np.ones(rot.shape[:2], dtype=bool)
+    if tag == "b":
+        keep[0, 5] = False
+    assert np.abs(rot - c["primrot"])[keep].max() <= 1e-14 and np.isfinite(rot).all()
+    gdu, gdv = po.prim_frame_backward(c["du"], c["dv"], c["g_primrot"].reshape(c["du"].shape[:-1] + (3, 3)))
+    for got, name in ((gdu, "g_du"), (gdv, "g_dv")):
+        ref, got = c[name].reshape(B, -1, 3), got.reshape(B, -1, 3)
+        assert np.abs(got - ref)[keep].max() <= 1e-9 * max(1.0, np.abs(ref[keep]).max()), (name, np.abs(got - ref)[keep].max())
+        assert np.isfinite(got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ("a", "b"))
+def test_frame_kernels_match_the_reference_lines(tag):
+    from ava256_amd.placement import prim_frame
+    c = _frame_case(tag)
+    du = torch.from_numpy(c["du"]).float().cuda().requires_grad_(True)
+    dv = torch.from_numpy(c["dv"]).float().cuda().requires_grad_(True)
+    rot = prim_frame(du, dv)
+    assert tuple(rot.shape) == c["primrot"].shape
+    # the clamped rows of case b divide by 1e-8: their entries are O(1e8 * eps) apart in fp32 -- compared relative to the row
+    ref = c["primrot"]
+    err = np.abs(rot.detach().cpu().numpy() - ref)
+    clamped = np.zeros(ref.shape[:2], dtype=bool)
+    if tag == "b":
+        clamped[0, 0] = True      # |du| = 0
+        clamped[0, 5] = True      # dv parallel to du (texel (1, 1) of a 4 x 4 grid)
+    assert err[~clamped].max() <= 2e-6
+    (torch.from_numpy(c["g_primrot"]).float().cuda() * rot).sum().backward()
+    for t, name in ((du, "g_du"), (dv, "g_dv")):
+        got, refg = t.grad.cpu().numpy().reshape(ref.shape[0], -1, 3), c[name].reshape(ref.shape[0], -1, 3)
+        scale = np.abs(refg[~clamped]).max()
+        assert np.abs(got - refg)[~clamped].max() <= 2e-5 * max(1.0, scale), name
+        assert np.isfinite(got).all()
+
+
+@pytest.mark.gpu
+def test_placement_frame_residuals_chain_is_the_assembler():
+    """prim_placement -> prim_frame -> prim_residuals = assembler.py:118-253 for 16384 primitives: against the oracles chained
+    the same way, on a seeded mesh (the three kernels hand [B, K, .] tensors to each other without a copy)."""
+    from oracle import placement_oracle as plo
+    from oracle import primpose_oracle as po
+    from ava256_amd.placement import prim_frame, prim_placement, prim_residuals
+    from helpers import make_placement_inputs
+    B, K = 2, 16384
+    geo, idxim, barim, volradius, _ = make_placement_inputs(K, B=B, V=500, seed=4)
+    dev = "cuda"
+    g = torch.from_numpy(geo).to(dev).requires_grad_(True)
+    pos0, du, dv = prim_placement(g, torch.from_numpy(idxim).to(dev), torch.from_numpy(barim).to(dev), volradius, K)
+    rot0 = prim_frame(du, dv)
+    rng = np.random.default_rng(2)
+    posres, rotres = (0.01 * rng.normal(size=(B, K, 3))).astype(np.float32), (0.2 * rng.normal(size=(B, K, 3))).astype(np.float32)
+    scaleres = (1 + 0.1 * rng.normal(size=(B, K, 3))).astype(np.float32)
+    scale0 = torch.full((1,), 64.0, device=dev)                                   # assembler.py:173 `primscale = 64.0`
+    pos, rot, scale = prim_residuals(pos0, rot0, scale0, *[torch.from_numpy(a).to(dev) for a in (posres, rotres, scaleres)], 0.5, B)
+    rp, rdu, rdv = plo.placement(geo.astype(np.float64), idxim, barim.astype(np.float64), volradius, K)
+    rrot0 = po.prim_frame(rdu, rdv).reshape(B, K, 3, 3)
+    ep, er, es = po.prim_residuals(rp.reshape(B, K, 3), rrot0, 64.0, posres.astype(np.float64), rotres.astype(np.float64),
+                                   scaleres.astype(np.float64), 0.5)
+    assert np.abs(pos.detach().cpu().numpy() - ep).max() <= 1e-5 * np.abs(ep).max()
+    assert np.abs(rot.detach().cpu().numpy() - er).max() <= 2e-4      # unit(du) of differences of nearby texels: fp32 cancellation
+    assert np.abs(scale.detach().cpu().numpy() - es).max() <= 1e-5 * np.abs(es).max()
+    (rot.sum() + pos.sum()).backward()
+    assert torch.isfinite(g.grad).all() and float(g.grad.abs().max()) > 0
