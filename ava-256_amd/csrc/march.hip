@@ -2701,14 +2701,44 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : MVP_BWD_OCC) void bwd_prim_kern
     bwd_prim_body<FADE8, TS, PW, WARP, false>(p, (int)blockIdx.x, smem4);
 }
 
-// The two-pass instantiation (general slab strides, 2 waves): a small persistent grid that walks the same block -> primitive
-// map and works only on the primitives the kernel above marked; returns at once when it marked none.
+// The two-pass instantiation (general slab strides): a small persistent grid that walks the same block -> primitive
+// map and works only on the primitives the kernel above marked; returns at once when it marked none.  kPreciseWaves waves per
+// workgroup: the marked primitives are few and LARGE (tens of thousands of samples each, marched twice), one per workgroup
+// at a time, so the kernel lasts as long as its largest primitive -- more waves on it, not more workgroups, shorten that.
+#ifndef MVP_PRECISE_WAVES
+#define MVP_PRECISE_WAVES 4
+#endif
+constexpr int kPreciseWaves = MVP_PRECISE_WAVES;
 template <bool FADE8, bool WARP>
-__global__ __launch_bounds__(128, 2) void bwd_prim_precise_kernel(const MarchParams p, const int total_blocks) {
+__global__ __launch_bounds__(kPreciseWaves * 64, 2) void bwd_prim_precise_kernel(const MarchParams p, const int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     if ((p.pl_count[(size_t)p.N * p.K] & kFlagBwdPrecise) == 0u) return;
-    for (int b = (int)blockIdx.x; b < total_blocks; b += (int)gridDim.x) {
-        bwd_prim_body<FADE8, 0, 2, WARP, true>(p, b, smem4);
+    // Which of this workgroup's blocks are marked: all its counters are looked at in ONE parallel sweep (the body's own test is a
+    // dependent global load + a barrier per block: ~160 blocks x ~2 us per workgroup at C2 when one or two of them have work)
+    constexpr int kTodo = 256;
+    __shared__ int s_todo[kTodo];
+    __shared__ int s_ntodo;
+    if (threadIdx.x == 0) s_ntodo = 0;
+    __syncthreads();
+    for (int b = (int)blockIdx.x + (int)threadIdx.x * (int)gridDim.x; b < total_blocks; b += (int)(blockDim.x * gridDim.x)) {
+        int n, k;
+        if (!prim_of_block(p, b, n, k)) continue;
+        const uint32_t c = p.pl_count[(size_t)n * p.K + k];
+        if ((c & (kCountPrecise | kCountDead)) != kCountPrecise) continue;
+        const int slot = atomicAdd(&s_ntodo, 1);
+        if (slot < kTodo) s_todo[slot] = b;
+    }
+    __syncthreads();
+    const int ntodo = s_ntodo;
+    if (ntodo > kTodo) {  // (more marked blocks than the table holds: the plain walk)
+        for (int b = (int)blockIdx.x; b < total_blocks; b += (int)gridDim.x) {
+            bwd_prim_body<FADE8, 0, kPreciseWaves, WARP, true>(p, b, smem4);
+            __syncthreads();
+        }
+        return;
+    }
+    for (int i = 0; i < ntodo; ++i) {
+        bwd_prim_body<FADE8, 0, kPreciseWaves, WARP, true>(p, s_todo[i], smem4);
         __syncthreads();  // (the next primitive restages the LDS this one's last readers may still be in)
     }
 }
@@ -3012,8 +3042,8 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
         rc = launch_status();
         if (rc != MVP_OK) return rc;
         {  // the two-pass instantiation for the primitives that kernel marked (heavy-tailed upstream gradients); exits at
-           // once otherwise.  Same LDS layout with 2 waves per workgroup.
-            size_t lds2 = V * 16 + Vp * 16 + (size_t)prim_queue_cap(2) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4 +
+           // once otherwise.  Same LDS layout with kPreciseWaves waves per workgroup.
+            size_t lds2 = V * 16 + Vp * 16 + (size_t)prim_queue_cap(kPreciseWaves) * 8 + 64 * sizeof(float) + 16 + kLenBuckets * 4 +
                           (((size_t)primlist_cap * 2 + 15) & ~(size_t)15);
             MarchParams p2 = p;
             if (warp) {
@@ -3022,7 +3052,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
                 const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + kGradPadZ);
                 lds2 += VW * 16 + VWp * 12;
             }
-            const dim3 g2((unsigned)(pb < 2048 ? pb : 2048)), b2(128);
+            const dim3 g2((unsigned)(pb < 2048 ? pb : 2048)), b2(kPreciseWaves * 64);
             if (warp && fade8)
                 hipLaunchKernelGGL((bwd_prim_precise_kernel<true, true>), g2, b2, lds2, st, p2, (int)pb);
             else if (warp)
