@@ -44,7 +44,10 @@ namespace mvp {
 
 constexpr int kTile = 8;          // 8x8 pixels per wave
 constexpr int kMaxList = 512;     // reference hit-list cap (mvpraymarch_kernel.cu:101, utils.h:779)
-constexpr int kRecSlots = 64;     // SRT records staged in LDS (first 64 candidates); beyond: scalar global loads
+#ifndef MVP_REC_SLOTS
+#define MVP_REC_SLOTS 64
+#endif
+constexpr int kRecSlots = MVP_REC_SLOTS;  // SRT records staged in LDS (first 64 candidates); beyond: scalar global loads
 constexpr int kStartDepth = 10;   // the BFS tests every node of this depth first (implicit frontier, <= 1024 nodes)
 constexpr int kNoSlot = 255;
 // Lane-independent forward sweep (see march_packet): per-ray crossing table in LDS, kFastCross rows of 64 lanes.
@@ -1590,7 +1593,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
 
 // TS > 0 (forward, no warp field): TS^3 slabs with compile-time strides, see sample_slab_c
 template <bool BWD, bool FADE8, bool WARP, int TS = 0>
-__global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
+#ifndef MVP_FWD_OCC
+#define MVP_FWD_OCC 1
+#endif
+__global__ __launch_bounds__(kWave, MVP_FWD_OCC) void march_kernel(const MarchParams p) {
     // One LDS block per wave: [SRT records: 64 x 64 B][region].  The region is the two 512-entry frontier / list arrays
     // (s_a, s_b); in the plain forward it is large enough to be re-used, after the traversal, as the per-ray crossing
     // table of the lane-independent sweep (kFastCross rows x 64 lanes x 4 B).
