@@ -1593,10 +1593,11 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
 
 // TS > 0 (forward, no warp field): TS^3 slabs with compile-time strides, see sample_slab_c
 template <bool BWD, bool FADE8, bool WARP, int TS = 0>
-#ifndef MVP_FWD_OCC
-#define MVP_FWD_OCC 1
-#endif
+#ifdef MVP_FWD_OCC  // timing variants only (profiles/r04_forward_experiments.json: six waves per SIMD)
 __global__ __launch_bounds__(kWave, MVP_FWD_OCC) void march_kernel(const MarchParams p) {
+#else
+__global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
+#endif
     // One LDS block per wave: [SRT records: 64 x 64 B][region].  The region is the two 512-entry frontier / list arrays
     // (s_a, s_b); in the plain forward it is large enough to be re-used, after the traversal, as the per-ray crossing
     // table of the lane-independent sweep (kFastCross rows x 64 lanes x 4 B).
