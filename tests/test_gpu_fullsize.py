@@ -38,7 +38,7 @@ def _assert_euler(template, grad_template, gout, rgba):
     """Euler homogeneity: rgb is linear in the slab rgb channels (alpha does not depend on them), so
     sum T_rgb * dL/dT_rgb = sum dL/drgb * rgb.  With random-sign upstream gradients both sides are sums of cancelling terms
     (C2, 8 cameras: 3.5e4 out of sum |terms| = 7.5e7), so the bound is stated against sum |terms|: 5e-7, fp32 level.  A
-    sample class missing from the backward shows at 1e-4 or more.  Measured (tools/debug_euler.py, gpurun_out/r03e): the
+    sample class missing from the backward shows at 1e-4 or more.  Measured (tools/diag_euler_residual.py, gpurun_out/r03e): the
     ray-centric backward (fp32 atomics) 2e-10; the primitive-centric one 1.1e-7 (round 2: 0.8e-7) -- v_cvt_rpi_i32_f32
     rounds ties upward, a coherent +2^-25 relative per contribution."""
     terms = template[..., :3].double() * grad_template[..., :3].double()

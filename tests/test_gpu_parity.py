@@ -191,7 +191,7 @@ FUZZ_ESCAPES = []   # (seed, which bound) of the draws that needed the fp32-orac
 
 
 def fuzz_draw(seed, oracle64):
-    """The seeded random configuration of test_randomized_configurations (also replayed by tools/debug_fuzz.py)."""
+    """The seeded random configuration of test_randomized_configurations (also replayed by tools/diag_fuzz_replay.py)."""
     from ava256_amd.scene import make_scene
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.integers(1, 4))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/debug_euler.py [library.so ...] -- the Euler-homogeneity residual of tests/test_gpu_fullsize.py::
+"""tools/diag_euler_residual.py [library.so ...] -- the Euler-homogeneity residual of tests/test_gpu_fullsize.py::
 test_c2_gradient_properties (sum T_rgb * dL/dT_rgb  vs  sum dL/drgb * rgb, 8 cameras of C2 at opacity x20) for the product
 library, for other builds of the same ABI, and for the ray-centric backward (fp32 global atomics): which part of the
 residual belongs to the accumulation scheme and which to the forward / backward pair itself."""

@@ -1,6 +1,6 @@
-"""tools/debug_fuzz.py <seed>... -- replay draws of tests/test_gpu_parity.py::test_randomized_configurations on the GPU
+"""tools/diag_fuzz_replay.py <seed>... -- replay draws of tests/test_gpu_parity.py::test_randomized_configurations on the GPU
 and, per primitive, put the slab-gradient error of every backward owner (primitive-centric, ray-centric, capacity 4)
-and of the fp32 oracle side by side against the float64 oracle.  (Debug tool; runs where tests/ and oracle/ are.)"""
+and of the fp32 oracle side by side against the float64 oracle.  (Diagnostic; runs where tests/ and oracle/ are: the oracle is the checker here as in the tests.)"""
 import os
 import sys
 

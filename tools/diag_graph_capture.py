@@ -1,4 +1,4 @@
-"""tools/debug_capture.py -- which operator of the training iteration refuses hipGraph capture (forward + backward of each
+"""tools/diag_graph_capture.py -- which operator of the training iteration refuses hipGraph capture (forward + backward of each
 piece captured on its own; prints ok / the error)."""
 import os
 import sys

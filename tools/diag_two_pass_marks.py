@@ -1,4 +1,4 @@
-"""tools/debug_precise.py [workload] -- how many primitives of a TRAINING iteration's backward go to the two-pass (residual)
+"""tools/diag_two_pass_marks.py [workload] -- how many primitives of a TRAINING iteration's backward go to the two-pass (residual)
 kernel or to the ray-centric kernel, and what the upstream gradient of the march looks like (why)."""
 import os
 import sys
