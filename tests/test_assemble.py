@@ -86,9 +86,40 @@ def test_frame_broadcast_form_equals_assemble_times_gain(cfg):
     gout = torch.randn(out.shape, device="cuda", generator=g)
     out.backward(gout)
     eager.backward(gout)
+    # the oracle (numpy float64, oracle/assemble_oracle.py: pinned to the reference's decoders by assemble_map.npz and, for the
+    # backward and the frame form, to autograd of the reference's statements by test_frame_oracle_equals_autograd...)
+    from oracle import assemble_oracle as ao
+    npf = lambda t: t.detach().cpu().numpy().astype(np.float64)   # noqa: E731
+    ref = ao.assemble_template_frames(npf(tex), npf(op), npf(gain), nh * nh, B)
+    assert np.abs(npf(out) - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max() if ref.size else 1.0)
+    if F > 0:
+        rt, ro, rg = ao.assemble_template_frames_backward(npf(tex), npf(op), npf(gain), nh * nh, B, npf(gout))
+        for got, want in ((tex.grad, rt), (op.grad, ro), (gain.grad, rg)):
+            assert np.abs(npf(got) - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
     for a, b in ((tex.grad, t2.grad), (op.grad, o2.grad), (gain.grad, g2.grad)):
         assert a.shape == b.shape and torch.isfinite(a).all()
         if F == 0:
             assert not a.any()
         else:
             assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, 4), (2, 4, 8)], ids=lambda c: "F%d_nh%d_B%d" % c)
+def test_frame_oracle_equals_autograd_of_the_reference_statements(cfg):
+    """oracle/assemble_oracle.assemble_template_backward / _frames / _frames_backward (hand-written) against torch autograd of
+    the reference's statements (rgb.py:137-143, geometry.py:183-185, assembler.py:261 as trainloop.assemble_template_eager
+    states them) times a per-frame gain, float64 on CPU."""
+    from oracle import assemble_oracle as ao
+    from ava256_amd.trainloop import assemble_template_eager
+    F, nh, B = cfg
+    S = nh * B
+    rng = np.random.default_rng(5)
+    tex, op = rng.normal(size=(1, 3 * B, S, S)) * 2 - 3.5, rng.normal(size=(1, B, S, S))
+    gain, g = 1 + 0.3 * rng.normal(size=F), rng.normal(size=(F, nh * nh, B, B, B, 4))
+    t, o, gn = (torch.tensor(a, requires_grad=True) for a in (tex, op, gain))
+    out = gn.view(-1, 1, 1, 1, 1, 1) * assemble_template_eager(t, o, nh * nh, B)
+    out.backward(torch.tensor(g))
+    assert np.abs(ao.assemble_template_frames(tex, op, gain, nh * nh, B) - out.detach().numpy()).max() <= 1e-13
+    gt, go, gg = ao.assemble_template_frames_backward(tex, op, gain, nh * nh, B, g)
+    assert np.abs(gt - t.grad.numpy()).max() <= 1e-12 and np.abs(go - o.grad.numpy()).max() <= 1e-12
+    assert np.abs(gg - gn.grad.numpy()).max() <= 1e-10 * max(1.0, np.abs(gg).max())
