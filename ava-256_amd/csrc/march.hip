@@ -653,6 +653,22 @@ __host__ __device__ inline bool prim_of_block(const MarchParams &p, int b, int &
     return n < p.N && k < K;
 }
 
+// LDS ordering point inside a packet.  One wave = one workgroup: a workgroup barrier (which is free there).  Timing variant
+// MVP_FWD_QUAD > 1 (several independent packets = waves per workgroup, so that neighbouring packets share a CU's L1): a fence
+// only -- every wave works in its own LDS block and a wave's LDS operations complete in order; an s_barrier would tie
+// packets with different trip counts together.
+#ifndef MVP_FWD_QUAD
+#define MVP_FWD_QUAD 1
+#endif
+__device__ __forceinline__ void packet_sync() {
+#if MVP_FWD_QUAD > 1
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#else
+    __syncthreads();
+#endif
+}
+
 template <bool BWD, bool FADE8, bool WARP, int TS>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
                                              uint32_t *s_tab, const bool emit_all) {
@@ -798,7 +814,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 frontier_ovf = true;
                 break;
             }
-            __syncthreads();
+            packet_sync();
             int *t = cur;
             cur = nxt;
             nxt = t;
@@ -812,7 +828,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             //      stack, every lane testing ITS ray against both children (utils.h:679-685), decisions OR-ed over
             //      the packet.  Slow (one dependent round trip per node) but capacity-free; only heavy scenes get here.
             if (p.diag && lane == 0) atomicAdd(p.diag + MVP_DIAG_FRONTIER_OVERFLOW, 1u);
-            __syncthreads();
+            packet_sync();
             int *stack = s_a;  // wave-uniform contents
             int *cand = s_b;
             const f3 irdl = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -862,10 +878,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             ++sp;
                         }
                     }
-                    __syncthreads();
+                    packet_sync();
                 }
             }
-            __syncthreads();
+            packet_sync();
             cur = cand;
         }
 
@@ -877,7 +893,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             if (fast) {
                 kk0 = lane < ncand ? (~cur[lane]) - (K - 1) : 0;
                 kk1 = lane + kWave < ncand ? (~cur[lane + kWave]) - (K - 1) : 0;
-                __syncthreads();
+                packet_sync();
             } else {
                 int kk[kMaxList / kWave];
 #pragma unroll
@@ -885,7 +901,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                     const int idx = c * kWave + lane;
                     kk[c] = idx < ncand ? (~cur[idx]) - (K - 1) : 0;
                 }
-                __syncthreads();
+                packet_sync();
 #pragma unroll
                 for (int c = 0; c < kMaxList / kWave; ++c) {
                     const int idx = c * kWave + lane;
@@ -897,7 +913,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             // over candidates, one gather round trip
             if (lane < ncand && lane < (fast ? kFastSlots : kRecSlots))
                 rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk0), kk0);
-            __syncthreads();
+            packet_sync();
         }
     }
 
@@ -1002,11 +1018,11 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             fast = false;
             rtmin = INFINITY, rtmax = -INFINITY;
             nh = 0;
-            __syncthreads();
+            packet_sync();
             if (lane < ncand) s_b[lane] = kk0;
             if (lane + kWave < ncand) s_b[lane + kWave] = kk1;
             if (lane < ncand && lane < kRecSlots) rec_to_lds(s_rec, lane, rec_from_global(pp, pr, ps, kk0), kk0);
-            __syncthreads();
+            packet_sync();
         }
     }
     for (int c = 0; c < ((FAST && fast) ? 0 : ncand); ++c) {
@@ -1045,7 +1061,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             }
         }
     }
-    __syncthreads();
+    packet_sync();
 
     if (MVP_DEBUG_STAGE(p) == 2) nh = 0;
     // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
@@ -1596,7 +1612,7 @@ template <bool BWD, bool FADE8, bool WARP, int TS = 0>
 #ifdef MVP_FWD_OCC  // timing variants only (profiles/r04_forward_experiments.json: six waves per SIMD)
 __global__ __launch_bounds__(kWave, MVP_FWD_OCC) void march_kernel(const MarchParams p) {
 #else
-__global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
+__global__ __launch_bounds__(BWD ? kWave : kWave * MVP_FWD_QUAD) void march_kernel(const MarchParams p) {
 #endif
     // One LDS block per wave: [SRT records: 64 x 64 B][region].  The region is the two 512-entry frontier / list arrays
     // (s_a, s_b); in the plain forward it is large enough to be re-used, after the traversal, as the per-ray crossing
@@ -1605,7 +1621,10 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     constexpr int kSlowWords = kRecSlots * 16 + 2 * kMaxList;
     constexpr int kFastWords = kFastSlots * 16 + kFastCross * kWave;
     constexpr int kWords = (!BWD && !WARP && kFastWords > kSlowWords) ? kFastWords : kSlowWords;
-    __shared__ __attribute__((aligned(16))) uint32_t smem[kWords];
+    constexpr int kQuad = BWD ? 1 : MVP_FWD_QUAD;  // packets (waves) per workgroup
+    __shared__ __attribute__((aligned(16))) uint32_t smem_all[kWords * kQuad];
+    const int qwave = kQuad > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    uint32_t *smem = smem_all + qwave * kWords;
     float4 *s_rec = reinterpret_cast<float4 *>(smem);
     int *s_a = reinterpret_cast<int *>(smem + kRecSlots * 16);
     int *s_b = s_a + kMaxList;
@@ -1621,8 +1640,14 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
             march_packet<BWD, FADE8, WARP, TS>(p, b, s_a, s_b, s_rec, s_tab, emit_all);
             __syncthreads();
         }
-    } else {
+    } else if (kQuad == 1) {
         march_packet<BWD, FADE8, WARP, TS>(p, blockIdx.x, s_a, s_b, s_rec, s_tab, true);
+    } else {
+        // block b runs on XCD b % 8: keep those three bits, the workgroup's waves take kQuad consecutive slots of that XCD's
+        // share (consecutive slots of a strip are neighbouring packets, packet_of_block)
+        const int ii = kQuad * ((int)blockIdx.x >> 3) + qwave;
+        if (ii < (p.total_packets >> 3))
+            march_packet<BWD, FADE8, WARP, TS>(p, ((int)blockIdx.x & 7) + 8 * ii, s_a, s_b, s_rec, s_tab, true);
     }
 }
 
@@ -2897,7 +2922,11 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
         if (e != hipSuccess) return (int)e;
     }
     const bool fade8 = fadeexp == 8.0f;
+#if MVP_FWD_QUAD > 1
+    const dim3 grid((unsigned)(8 * (((p.total_packets >> 3) + MVP_FWD_QUAD - 1) / MVP_FWD_QUAD))), block(kWave * MVP_FWD_QUAD);
+#else
     const dim3 grid((unsigned)p.total_packets), block(kWave);
+#endif
     if (warp) {
         if (fade8)
             hipLaunchKernelGGL((march_kernel<false, true, true>), grid, block, 0, st, p);
