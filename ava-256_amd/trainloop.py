@@ -521,7 +521,9 @@ class Trainer:
         iteration -- forward, losses, backward, gradient hygiene, Adam -- is captured once into a hipGraph and replayed: one
         launch per iteration instead of ~350 (the stand-in's small tensors make the eager loop host-bound at C3).  A change of
         the forward schedule (ddp-train.py:371-377, at iteration 100) captures a second graph; the learning-rate schedule
-        writes a device scalar the captured Adam reads."""
+        writes a device scalar the captured Adam reads.  In graph mode `step` returns the graph's OWN output tensors (loss, loss
+        parts, `last_grad_norm`): the next replay overwrites them -- read or clone them before the next `step`; the batch must
+        keep its shapes (its tensors are copied into the graph's inputs)."""
         self.raw_model = model
         if ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
