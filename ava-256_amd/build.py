@@ -7,9 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvp_gfx950.so")
-SOURCES = ["raydirs.hip", "aabb.hip", "march.hip", "assemble.hip", "placement.hip", "gradclip.hip", "bgmlp.hip", "pixeltail.hip", "primpose.hip", "abi_misc.hip"]
-HEADERS = [os.path.join(CSRC, "mvp_device.h"), os.path.join(CSRC, "mvp_host.h"),
-           os.path.join(ROOT, "include", "mvp_abi.h")]
+SOURCES = ["raydirs.hip", "aabb.hip", "march_fwd.hip", "march_bwd.hip", "march_host.hip", "assemble.hip", "placement.hip", "gradclip.hip", "bgmlp.hip", "pixeltail.hip", "primpose.hip", "abi_misc.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("mvp_device.h", "mvp_host.h", "march_common.h", "march_packet.h")] + [
+    os.path.join(ROOT, "include", "mvp_abi.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

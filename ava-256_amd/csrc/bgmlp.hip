@@ -32,10 +32,6 @@
 #include "mvp_device.h"
 #include "mvp_host.h"
 
-#ifndef BG_EXP
-#define BG_EXP 0  // timing experiments (wrong results by construction): 1 no epilogue, 2 no MFMA, 3 no k-loop barriers, 4 no LDS fragment reads
-#endif
-
 namespace mvp {
 namespace bgmlp {
 
@@ -85,10 +81,7 @@ __device__ __forceinline__ const __bf16 *chunk_ptr(const Params &p, int g, int t
 }
 constexpr int kFwdChunks = kK0 / kChunk + kHidden * (kWidth / kChunk);  // 67
 constexpr int kBwdChunks = kHidden * (kWidth / kChunk);                 // 64
-#ifndef BG_QUEUE
-#define BG_QUEUE 4
-#endif
-constexpr int kQueue = BG_QUEUE;  // chunks in flight per thread (registers), i.e. an L2 round trip is covered by ~4 k-steps of MFMA
+constexpr int kQueue = 4;  // chunks in flight per thread (registers), i.e. an L2 round trip is covered by ~4 k-steps of MFMA
 
 // acc[mi][ni] = (X[64 mq + 32 mi .., :K] . W[128 nh + 32 ni .., :K]^T)^T for the layer whose weights are chunks
 // G0 .. G0 + K/16 - 1 of the stream.  The MFMA is issued with the WEIGHT fragment as A and the activation fragment as B,
@@ -133,34 +126,19 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
     MVP_FRAGS(a[0], b[0], 0)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-#if BG_EXP != 3
         if (c > 0) __syncthreads();
-#endif
         if (c + 2 < NC) MVP_STAGE(G0 + c + 2)
-#if BG_EXP != 4
         if (c + 1 < NC) MVP_FRAGS(a[(c + 1) & 1], b[(c + 1) & 1], c + 1)
-#else
-        a[(c + 1) & 1][0] = a[c & 1][1], a[(c + 1) & 1][1] = a[c & 1][0];
-        b[(c + 1) & 1][0] = b[c & 1][1], b[(c + 1) & 1][1] = b[c & 1][2], b[(c + 1) & 1][2] = b[c & 1][3], b[(c + 1) & 1][3] = b[c & 1][0];
-#endif
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-#if BG_EXP == 2
-                if (c == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-                }
-                acc[mi][ni][c & 15] += (float)b[c & 1][ni][mi] * (float)a[c & 1][mi][ni];
-#else
                 if (c == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0][ni], a[0][mi], zero, 0, 0, 0);
                 } else {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c & 1][ni], a[c & 1][mi], acc[mi][ni], 0, 0, 0);
                 }
-#endif
             }
     }
 #undef MVP_STAGE
@@ -172,19 +150,6 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
 template <bool ACT>
 __device__ __forceinline__ void acc_to_lds(__bf16 *X, const f32x16 (&acc)[2][4], const float *__restrict__ bias, int mq,
                                            int nh, int lane) {
-#if BG_EXP == 1
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[mi][ni][r];
-        if (t == 123.456f) X[lane] = (__bf16)t;
-        return;
-    }
-#endif
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll

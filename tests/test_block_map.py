@@ -1,4 +1,4 @@
-"""CPU test of the march kernels' block -> work mapping (csrc/march.hip: packet_of_block / prim_of_block), evaluated on
+"""CPU test of the march kernels' block -> work mapping (csrc/march_common.h: packet_of_block / prim_of_block), evaluated on
 the host through mvp_march_block_map -- the same functions the kernels call.  For many (N, H, W, K): every (image, packet)
 and every (image, primitive) is produced by exactly one block; whole images sit on one XCD (block % 8); shared images
 use all the XCDs their split says."""

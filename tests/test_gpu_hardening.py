@@ -189,7 +189,7 @@ def test_warp_field_backward_is_reproducible(ops):
 def test_block_to_image_mapping_with_eight_or_more_images(ops, oracle64, N, mode):
     """Blocks are mapped to (image, packet) / (image, primitive) in two regimes: the first N - N % 8 images go whole to
     one XCD each (image x, x + 8, ... on XCD x), the other R = N % 8 are shared by F XCDs each (2 for R = 4, 4 for R = 2,
-    else 8) with 8 / F of them in flight (csrc/march.hip).  N = 8: whole only; 5: five shared images in five rounds;
+    else 8) with 8 / F of them in flight (csrc/march_common.h: packet_of_block / prim_of_block).  N = 8: whole only; 5: five shared images in five rounds;
     10 (F = 4) and 17 (F = 8): both regimes in one grid; every image, ragged packets included, must match the oracle.
     (The other tests run N = 1..4: F = 8, 4, 8, 2.)"""
     from ava256_amd.scene import make_scene

@@ -1,4 +1,4 @@
-"""With the MVP_EXP=4 library: LDS scatter statistics of the primitive-centric backward at a bench workload."""
+"""With the MVP_EXP=4 library (tools/exp_variants.sh 4; bind it with ava256_amd._lib.use_library): LDS scatter statistics of the primitive-centric backward at a bench workload."""
 import sys, torch
 sys.path.insert(0, "."); import bench
 import ava256_amd as ops

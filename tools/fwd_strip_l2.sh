@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/fwd_strip_l2.sh <tag> -- forward march at C2 with dispatch strips of 1 / 2 / 3 (product) / 4 / 6 packet rows
-# (build_variants/libmvp_strip<r>.so, -DMVP_STRIP_ROWS=r): time, L2 hit rate and HBM read traffic per launch.  Question: does a
+# (build_variants/libmvp_strip<r>.so = tools/build_patched.sh strip<r> profiles/r05_timing_variants.patch -DMVP_STRIP_ROWS=r): time, L2 hit rate and HBM read traffic per launch.  Question: does a
 # strip height whose in-flight slabs fit the XCD's 4 MB L2 remove the 1.78x over-fetch, and does that matter?
 set -u
 TAG=$1

@@ -1,14 +1,15 @@
 #!/bin/bash
-# tools/kernel_resources.sh -- per-kernel register / LDS / scratch usage of every HIP source (compiled for gfx950 exactly
-# as build.py does: keep the code-generation flags below equal to build.py's FLAGS), from the code-object metadata.  Output: profiles/kernel_resources.csv
+# tools/kernel_resources.sh -- (from SOURCE; tools/kernel_resources.py reads the same table out of the built library in
+# half a second and is what tests/test_build_hygiene.py and /tmp/kernel_resources_from_source.csv use) per-kernel register / LDS / scratch usage of every HIP source (compiled for gfx950 exactly
+# as build.py does: keep the code-generation flags below equal to build.py's FLAGS), from the code-object metadata.  Output: /tmp/kernel_resources_from_source.csv
 set -eu
 cd "$(dirname "$0")/.."
 TMP=$(mktemp -d)
-echo "source,kernel,vgpr,vgpr_spill,sgpr,sgpr_spill,lds_bytes,scratch_bytes,waves_per_simd_by_vgpr" > profiles/kernel_resources.csv
-for f in raydirs aabb march assemble placement gradclip bgmlp pixeltail primpose abi_misc; do
+echo "source,kernel,vgpr,vgpr_spill,sgpr,sgpr_spill,lds_bytes,scratch_bytes,waves_per_simd_by_vgpr" > /tmp/kernel_resources_from_source.csv
+for f in raydirs aabb march_fwd march_bwd assemble placement gradclip bgmlp pixeltail primpose abi_misc; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -I include -I ava-256_amd/csrc -S --cuda-device-only \
         ava-256_amd/csrc/$f.hip -o $TMP/$f.s 2>/dev/null
-  python3 - "$TMP/$f.s" "$f" >> profiles/kernel_resources.csv <<'PY'
+  python3 - "$TMP/$f.s" "$f" >> /tmp/kernel_resources_from_source.csv <<'PY'
 import re, sys, subprocess
 txt = open(sys.argv[1]).read()
 meta = txt[txt.index("amdhsa.kernels:"):] if "amdhsa.kernels:" in txt else ""
@@ -24,4 +25,4 @@ for blk in meta.split("  - .agpr_count:")[1:]:
 PY
 done
 rm -rf $TMP
-cat profiles/kernel_resources.csv
+cat /tmp/kernel_resources_from_source.csv
