@@ -9,6 +9,7 @@ Only what the path needs lives here:
   raymarcher.py    Raymarcher nn.Module                      (reference: models/raymarchers/mvpraymarcher.py:17-54)
   native_shim.py   `mvpraymarchlib` / `utilslib` with the reference's positional signatures (mvpraymarch.cpp:146-405,
                    utils.cpp:46-137) over the C ABI: the reference's unmodified Python glue can bind to this build
+  halfslab.py      opt-in RENDER path over fp16 RGBA slabs (round 5): template_to_half, assemble_template_half, render_half*
   assemble.py      fused decoder -> raymarch template assembly  (rgb.py:137-143, assembler.py:261)
   placement.py     primitive placement on the mesh, 3 texels per primitive (row N2; assembler.py:118-122,143-206)
   gradclip.py      multi-tensor NaN/Inf masking + gradient clipping (row N4; ddp-train.py:434-441)

@@ -35,6 +35,12 @@ SIGNATURES = {
 SIGNATURES["mvp_march_forward_cams"] = (_c_int, [_c_int] * 4 + [_c_void_p] * 5 + [_c_float] * 2 + [_c_void_p] * 4 +
                                         [_c_int] * 3 + [_c_void_p] * 6 + [_c_int] + [_c_void_p] * 3 + [_c_float] * 2 +
                                         [_c_void_p] * 2)
+# N,H,W,K | raypos,raydir,tminmax | campos,camrot,focal,princpt,pixelcoords | volradius,stepsize |
+# nodeaabb,primpos,primrot,primscale | TD,TH,TW | tplate_half,rayrgba | fadescale,fadeexp | diag,stream
+SIGNATURES["mvp_march_render_half"] = (_c_int, [_c_int] * 4 + [_c_void_p] * 8 + [_c_float] * 2 + [_c_void_p] * 4 + [_c_int] * 3 +
+                                       [_c_void_p] * 2 + [_c_float] * 2 + [_c_void_p] * 2)
+SIGNATURES["mvp_template_to_half"] = (_c_int, [ctypes.c_longlong] + [_c_void_p] * 3)
+SIGNATURES["mvp_template_assemble_forward_half"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 4)
 SIGNATURES["mvp_template_assemble_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 5)
 # nh,B -> blocks | F,nh,B | tex,opacity,gain | tplate | stream | F,nh,B | tex,opacity,gain,grad_tplate | gtex,gop,partials | stream
@@ -73,7 +79,7 @@ SIGNATURES["mvp_pixel_tail_blocks"] = (_c_int, [_c_int] * 2)
 SIGNATURES["mvp_pixel_tail_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 8 + [_c_void_p])
 # N,H,W | rayrgba,cw,bg,target,irgbrec,g_irgbrec,g_ialpha,g_l1 | grad_rayrgba,grad_bg,cwcb_partials | stream
 SIGNATURES["mvp_pixel_tail_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 11 + [_c_void_p])
-ABI_VERSION = 14
+ABI_VERSION = 15
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -70,6 +70,34 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(int N, int nh, int B,
         texel_value(tex + (size_t)n * 3 * B * t.plane, opac + (size_t)n * B * t.plane, t);
 }
 
+// ---- half-precision slabs for the opt-in render path (march_common.h: sample_slab_h) -------------------------------------
+// fp16 RGBA, 8 bytes per voxel, round to nearest even (v_cvt_f16_f32); values beyond 65504 become +-inf like any fp16 cast
+// (slab values are relu(x * 25 + 100): hundreds).  Same thread mapping as above: eight consecutive lanes write one 64-byte
+// slab row.  Written straight from the decoder outputs, the half slab costs 16 B read + 8 B written per voxel; converting
+// an existing fp32 slab tensor (mvp_template_to_half) 16 + 8 as well.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h4 to_half4(float4 v) { return h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+
+__global__ __launch_bounds__(256) void assemble_fwd_half_kernel(int N, int nh, int B, const float *__restrict__ tex,
+                                                                const float *__restrict__ opac, h4 *__restrict__ tplate) {
+    const int n = (int)blockIdx.z / B;
+    Texel t;
+    if (!texel_of_thread(nh, B, (int)blockIdx.z - n * B, t)) return;
+    const size_t fstride = (size_t)nh * nh * B * B * B;
+    tplate[(size_t)n * fstride + t.vo] = to_half4(texel_value(tex + (size_t)n * 3 * B * t.plane, opac + (size_t)n * B * t.plane, t));
+}
+
+// two voxels per thread: 32 bytes read, 16 written
+__global__ __launch_bounds__(256) void template_to_half_kernel(size_t pairs, const float4 *__restrict__ src,
+                                                               float4 *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pairs) return;
+    const float4 a = src[2 * i], b = src[2 * i + 1];
+    union { h4 h[2]; float4 f; } u;
+    u.h[0] = to_half4(a), u.h[1] = to_half4(b);
+    dst[i] = u.f;
+}
+
 // grad_tex = 25 * g_rgb * [tplate_rgb > 0], grad_opacity = g_a * [tplate_a > 0]  (relu'(u) = [relu(u) > 0], as torch)
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(int N, int nh, int B, const float *__restrict__ tplate,
                                                            const float *__restrict__ gtpl,
@@ -235,5 +263,33 @@ extern "C" int mvp_template_assemble_frames_backward(int F, int nh, int B, const
     const size_t lds = (size_t)(bx / 64) * (size_t)(F > 0 ? F : 1) * sizeof(float);
     hipLaunchKernelGGL(assemble_frames_bwd_kernel, grid, dim3(bx), lds, (hipStream_t)stream, F, nh, B, tex, opacity, gain,
                        grad_tplate, grad_tex, grad_opacity, gain_partials);
+    return launch_status();
+}
+
+extern "C" int mvp_template_assemble_forward_half(int N, int nh, int B, const float *tex, const float *opacity,
+                                                  void *tplate_half, void *stream) {
+    using namespace mvp;
+    int rc = assemble_args_ok(N, nh, B);
+    if (rc != MVP_OK) return rc;
+    const long long S = (long long)nh * B;
+    if ((long long)N * B * S == 0) return MVP_OK;
+    if (!tex || !opacity || !tplate_half || !aligned16(tplate_half)) return MVP_ERR_BADARG;
+    if ((long long)N * B > 65535 || S > 65535) return MVP_ERR_UNSUPPORTED;
+    const int bx = assemble_block(S);
+    const dim3 grid((unsigned)((S + bx - 1) / bx), (unsigned)S, (unsigned)(N * B));
+    hipLaunchKernelGGL(assemble_fwd_half_kernel, grid, dim3(bx), 0, (hipStream_t)stream, N, nh, B, tex, opacity,
+                       reinterpret_cast<h4 *>(tplate_half));
+    return launch_status();
+}
+
+extern "C" int mvp_template_to_half(long long voxels, const float *tplate, void *tplate_half, void *stream) {
+    using namespace mvp;
+    if (voxels < 0 || (voxels & 1)) return MVP_ERR_BADARG;  // (slabs have an even number of voxels)
+    if (voxels == 0) return MVP_OK;
+    if (!tplate || !tplate_half || !aligned16(tplate) || !aligned16(tplate_half)) return MVP_ERR_BADARG;
+    const size_t pairs = (size_t)voxels / 2;
+    if ((pairs + 255) / 256 > 0x7fffffffull) return MVP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(template_to_half_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pairs,
+                       reinterpret_cast<const float4 *>(tplate), reinterpret_cast<float4 *>(tplate_half));
     return launch_status();
 }

@@ -491,6 +491,42 @@ __device__ __forceinline__ float4 sample_slab_c(const float *__restrict__ Timg, 
     return v;
 }
 
+// ---- half-precision slabs (opt-in render path, round 5) -----------------------------------------------------------
+// The forward's sweep is bound by the texture addresser, which charges per lane-gather: eight 16-byte gathers
+// per sample.  With the slab stored as fp16 RGBA (8 bytes per voxel, 4 KB per 8^3 slab: mvp_template_to_half,
+// mvp_template_assemble_forward_half) the two x-neighbours of a corner pair are 16 CONTIGUOUS bytes (8-byte aligned, never
+// across a 64-byte slab row), so a sample is FOUR 16-byte gathers over half the bytes.  Weights, interpolation and
+// compositing stay fp32: every product is v_fma_mix_f32 (fp16 operand widened inside the instruction, fp32 accumulate), in
+// the corner order of the fp32 sampler.  The only difference from the fp32 path is the storage rounding of the slab itself
+// (2^-11 relative per voxel value): against the oracle run ON THE ROUNDED SLABS the kernel meets the standing forward
+// tolerance (tests/test_gpu_half.py).
+typedef _Float16 h8 __attribute__((ext_vector_type(8), aligned(8)));
+template <bool FADE8, int TS>
+__device__ __forceinline__ float4 sample_slab_h(const void *__restrict__ Timg, uint32_t kbyte, f3 y, float fadescale,
+                                                float fadeexp) {
+#pragma clang fp contract(off)
+    const float fade = fade_pinned<FADE8>(y, fadescale, fadeexp);
+    const TriF t = tri_setup_f<TS>(y);                       // (t.off counts 16-byte voxels: half of it here)
+    constexpr int bH = TS * 8, bD = TS * TS * 8;             // byte strides of the fp16 slab
+    const char *pc = reinterpret_cast<const char *>(Timg) + (size_t)(kbyte + (t.off >> 1));
+    // one 16-byte gather per (y, z) corner pair: [0..3] = rgba at x0, [4..7] = rgba at x0 + 1
+    const h8 p00 = *reinterpret_cast<const h8 *>(pc), p01 = *reinterpret_cast<const h8 *>(pc + bH);
+    const h8 p10 = *reinterpret_cast<const h8 *>(pc + bD), p11 = *reinterpret_cast<const h8 *>(pc + bD + bH);
+    float4 v;
+#define MVP_HSUM(C_)                                                                                          \
+    __builtin_fmaf((float)p11[4 + C_], t.W11.y,                                                               \
+    __builtin_fmaf((float)p11[C_], t.W11.x,                                                                   \
+    __builtin_fmaf((float)p10[4 + C_], t.W10.y,                                                               \
+    __builtin_fmaf((float)p10[C_], t.W10.x,                                                                   \
+    __builtin_fmaf((float)p01[4 + C_], t.W01.y,                                                               \
+    __builtin_fmaf((float)p01[C_], t.W01.x,                                                                   \
+    __builtin_fmaf((float)p00[4 + C_], t.W00.y, (float)p00[C_] * t.W00.x)))))))
+    v.x = MVP_HSUM(0), v.y = MVP_HSUM(1), v.z = MVP_HSUM(2), v.w = MVP_HSUM(3);
+#undef MVP_HSUM
+    v.w = v.w * fade;
+    return v;
+}
+
 // ---- warp-field path (algo 1: PrimSamplerTW<true>, primsampler.h:53-58,82-88) -------------------------------------
 // The warped coordinate y1 may leave (-1,1)^3, so the template lookup needs the reference's general form: normalised
 // coordinate clamped to +-100, floor, zero padding through per-corner bounds tests (utils.h:414-498).

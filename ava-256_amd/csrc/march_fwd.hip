@@ -1,5 +1,5 @@
 // march_fwd.hip -- C-ABI entry points of the forward march (include/mvp_abi.h: mvp_march_forward,
-// mvp_march_forward_cams) and the instantiations of march_kernel<false, ..> they launch.
+// mvp_march_forward_cams, mvp_march_render_half) and the instantiations of march_kernel<false, ..> they launch.
 //   /root/reference/extensions/mvpraymarch/mvpraymarch.cpp:38-66 (raymarch_forward_cuda), mvpraymarch_kernel.cu:35-120
 #include "march_packet.h"
 
@@ -14,9 +14,14 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
                               const float *primrot, const float *primscale, int TD, int TH, int TW,
                               const float *tplate, int WD, int WH, int WW, const float *warp, float *rayrgba,
                               float *raysat, uint32_t *rayaux, uint32_t *primlist_count, uint32_t *primlist,
-                              int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream) {
+                              int primlist_cap, float fadescale, float fadeexp, uint32_t *diag, void *stream,
+                              bool half_slabs = false) {
     using namespace mvp;
     MarchParams p = {};
+    if (half_slabs) {  // the opt-in render path over fp16 RGBA slabs: forward only, nothing handed to a backward, 8^3 slabs
+        if (warp || raysat || rayaux || primlist_count || primlist) return MVP_ERR_BADARG;
+        if (TD != 8 || TH != 8 || TW != 8 || (unsigned long long)K * 4096ull >= (1ull << 32)) return MVP_ERR_UNSUPPORTED;
+    }
     if (cams) {
         p.campos = cams->campos, p.camrot = cams->camrot, p.focal = cams->focal, p.princpt = cams->princpt;
         p.pixelcoords = cams->pixelcoords, p.volradius = cams->volradius;
@@ -68,6 +73,11 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
             hipLaunchKernelGGL((march_kernel<false, true, true>), grid, block, 0, st, p);
         else
             hipLaunchKernelGGL((march_kernel<false, false, true>), grid, block, 0, st, p);
+    } else if (half_slabs) {
+        if (fade8)
+            hipLaunchKernelGGL((march_half_kernel<true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((march_half_kernel<false>), grid, block, 0, st, p);
     } else {
         // the reference's slab size (and BASELINE's) gets compile-time strides and 32-bit slab offsets
         const bool cube8 = TD == 8 && TH == 8 && TW == 8 && (unsigned long long)K * 8192ull < (1ull << 32);
@@ -106,4 +116,28 @@ extern "C" int mvp_march_forward_cams(int N, int H, int W, int K, const float *c
     return march_forward_impl(N, H, W, K, nullptr, nullptr, &cams, stepsize, nullptr, nodeaabb, primpos, primrot,
                               primscale, TD, TH, TW, tplate, 0, 0, 0, nullptr, rayrgba, raysat, rayaux, primlist_count,
                               primlist, primlist_cap, fadescale, fadeexp, diag, stream);
+}
+
+// The opt-in render path: the forward march over HALF-PRECISION slabs (fp16 RGBA, 8 bytes per voxel; made by
+// mvp_template_to_half or mvp_template_assemble_forward_half).  Rays either as tensors (campos == NULL) or made inside the
+// march from the cameras (raypos == raydir == tminmax == NULL), like the two fp32 entry points.  Forward only: no raysat,
+// no hand-off -- a training step uses the fp32 path.  8^3 slabs.
+extern "C" int mvp_march_render_half(int N, int H, int W, int K, const float *raypos, const float *raydir,
+                                     const float *tminmax, const float *campos, const float *camrot, const float *focal,
+                                     const float *princpt, const float *pixelcoords, float volradius, float stepsize,
+                                     const float *nodeaabb, const float *primpos, const float *primrot,
+                                     const float *primscale, int TD, int TH, int TW, const void *tplate_half,
+                                     float *rayrgba, float fadescale, float fadeexp, uint32_t *diag, void *stream) {
+    if (K > 0 && (!tplate_half || ((uintptr_t)tplate_half & 15u))) return MVP_ERR_BADARG;
+    const float *tp = reinterpret_cast<const float *>(tplate_half);  // (MarchParams carries one slab pointer)
+    if (campos) {
+        if (raypos || raydir || tminmax) return MVP_ERR_BADARG;
+        const CameraArgs cams = {campos, camrot, focal, princpt, pixelcoords, volradius, nullptr, nullptr, nullptr};
+        return march_forward_impl(N, H, W, K, nullptr, nullptr, &cams, stepsize, nullptr, nodeaabb, primpos, primrot,
+                                  primscale, TD, TH, TW, tp, 0, 0, 0, nullptr, rayrgba, nullptr, nullptr, nullptr, nullptr, 0,
+                                  fadescale, fadeexp, diag, stream, true);
+    }
+    return march_forward_impl(N, H, W, K, raypos, raydir, nullptr, stepsize, tminmax, nodeaabb, primpos, primrot, primscale,
+                              TD, TH, TW, tp, 0, 0, 0, nullptr, rayrgba, nullptr, nullptr, nullptr, nullptr, 0, fadescale,
+                              fadeexp, diag, stream, true);
 }

@@ -11,7 +11,8 @@ namespace mvp {
 // profiles/r04_fwd_ab_quad.txt, profiles/r05_timing_variants.patch.)
 __device__ __forceinline__ void packet_sync() { __syncthreads(); }
 
-template <bool BWD, bool FADE8, bool WARP, int TS>
+// HALF (forward, TS > 0, no warp field, no hand-off): p.tplate points at fp16 RGBA slabs (sample_slab_h)
+template <bool BWD, bool FADE8, bool WARP, int TS, bool HALF = false>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
                                              uint32_t *s_tab, const bool emit_all) {
     constexpr bool FAST = !BWD && !WARP;  // the lane-independent sweep exists for the plain forward only
@@ -464,6 +465,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         }
         const size_t V4 = (size_t)p.TD * p.TH * p.TW * 4;
         const float *T = p.tplate + (size_t)n * K * V4;
+        // (HALF: the same pointer addresses fp16 RGBA slabs, 8 bytes per voxel)
+        const char *Th = reinterpret_cast<const char *>(p.tplate) + (size_t)n * K * (V4 * 2);
         float *gT = BWD ? p.grad_tplate + (size_t)n * K * V4 : nullptr;
         const int sW = 4, sH = p.TW * 4, sD = p.TH * p.TW * 4;  // float strides of the channels-last slab
         const float mx = 0.5f * (float)(p.TW - 1), my = 0.5f * (float)(p.TH - 1), mz = 0.5f * (float)(p.TD - 1);
@@ -526,7 +529,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                         if (s >= incs && strictly_inside(yp)) {
                             const f3 y = mk3(yp.xy.x, yp.xy.y, yp.z);
                             float4 v;
-                            if constexpr (TS > 0)
+                            if constexpr (HALF)
+                                v = sample_slab_h<FADE8, TS>(Th, (uint32_t)k * (uint32_t)(TS * TS * TS * 8), y, p.fadescale,
+                                                             p.fadeexp);
+                            else if constexpr (TS > 0)
                                 v = sample_slab_c<FADE8, TS>(T, (uint32_t)k * (uint32_t)(TS * TS * TS * 16), y, p.fadescale,
                                                              p.fadeexp);
                             else
@@ -621,7 +627,10 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                                     v = tplate_lookup_general(T + (size_t)k * V4, y1, p.TD, p.TH, p.TW);
                                     v.w *= fade_of<FADE8>(y, p.fadescale, p.fadeexp);
                                 } else {
-                                    if constexpr (TS > 0)
+                                    if constexpr (HALF)
+                                        v = sample_slab_h<FADE8, TS>(Th, (uint32_t)k * (uint32_t)(TS * TS * TS * 8), y,
+                                                                     p.fadescale, p.fadeexp);
+                                    else if constexpr (TS > 0)
                                         v = sample_slab_c<FADE8, TS>(T, (uint32_t)k * (uint32_t)(TS * TS * TS * 16), y,
                                                                      p.fadescale, p.fadeexp);
                                     else
@@ -978,6 +987,20 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     } else {
         march_packet<BWD, FADE8, WARP, TS>(p, blockIdx.x, s_a, s_b, s_rec, s_tab, true);
     }
+}
+
+// The opt-in render path over fp16 slabs (8^3 only): forward without hand-off, see sample_slab_h.
+template <bool FADE8>
+__global__ __launch_bounds__(kWave) void march_half_kernel(const MarchParams p) {
+    constexpr int kSlowWords = kRecSlots * 16 + 2 * kMaxList;
+    constexpr int kFastWords = kFastSlots * 16 + kFastCross * kWave;
+    constexpr int kWords = kFastWords > kSlowWords ? kFastWords : kSlowWords;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[kWords];
+    float4 *s_rec = reinterpret_cast<float4 *>(smem);
+    int *s_a = reinterpret_cast<int *>(smem + kRecSlots * 16);
+    int *s_b = s_a + kMaxList;
+    uint32_t *s_tab = smem + kFastSlots * 16;
+    march_packet<false, FADE8, false, 8, true>(p, blockIdx.x, s_a, s_b, s_rec, s_tab, true);
 }
 
 }  // namespace mvp

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 14
+#define MVP_ABI_VERSION 15
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -117,6 +117,24 @@ int mvp_march_forward_cams(int N, int H, int W, int K, const float *campos /*[N,
                            float *raypos_out /*or NULL*/, float *raydir_out /*or NULL*/, float *tminmax_out /*or NULL*/,
                            float fadescale, float fadeexp, uint32_t *diag, void *stream);
 
+/* Opt-in render path over HALF-PRECISION slabs (round 5; no counterpart in the reference, whose kernels read fp32 slabs:
+ * primsampler.h:44-66, utils.h:408-502).  tplate_half is [N,K,8,8,8,4] fp16 RGBA (8 bytes per voxel), made by
+ * mvp_template_to_half or mvp_template_assemble_forward_half below.  Same sample set, weights, interpolation and
+ * compositing as mvp_march_forward in fp32 arithmetic; the only difference is the storage rounding of the slab values
+ * (2^-11 relative).  The forward's sweep is bound by the texture path per lane-gather: the fp16 layout makes the two x
+ * neighbours of a corner pair one 16-byte gather -- 4 gathers per sample instead of 8, over half the bytes.
+ * Rays: either tensors (raypos, raydir, tminmax; campos == NULL) or made inside the march (campos .. princpt, optional
+ * pixelcoords, volradius; raypos == raydir == tminmax == NULL).  Forward only (no raysat, no hand-off to a backward);
+ * 8^3 slabs, else MVP_ERR_UNSUPPORTED. */
+int mvp_march_render_half(int N, int H, int W, int K, const float *raypos, const float *raydir, const float *tminmax,
+                          const float *campos, const float *camrot, const float *focal, const float *princpt,
+                          const float *pixelcoords, float volradius, float stepsize, const float *nodeaabb,
+                          const float *primpos, const float *primrot, const float *primscale, int TD, int TH, int TW,
+                          const void *tplate_half, float *rayrgba, float fadescale, float fadeexp, uint32_t *diag,
+                          void *stream);
+/* fp32 slab tensor -> fp16 (round to nearest even), `voxels` = N*K*TD*TH*TW (even).  16 B read + 8 B written per voxel. */
+int mvp_template_to_half(long long voxels, const float *tplate, void *tplate_half, void *stream);
+
 /* Backward march.  Replaces raymarch_backward_cuda (mvpraymarch.cpp:68-100, mvpraymarch_kernel.cu:122-207,
  * mvpraymarch_subset_kernel.h:102-216).  The four grad buffers are OVERWRITTEN (every element is written; the
  * caller need not zero-fill them, unlike mvpraymarch.py:240-246).  With the forward's hand-off buffers the
@@ -170,6 +188,10 @@ int mvp_template_assemble_forward(int N, int nh, int B, const float *tex, const 
                                   void *stream);
 int mvp_template_assemble_backward(int N, int nh, int B, const float *tplate, const float *grad_tplate,
                                    float *grad_tex, float *grad_opacity, void *stream);
+/* The same forward writing fp16 RGBA slabs [N, nh*nh, B, B, B, 4] for mvp_march_render_half: the values of
+ * mvp_template_assemble_forward rounded to nearest even, 8 bytes written per voxel instead of 16. */
+int mvp_template_assemble_forward_half(int N, int nh, int B, const float *tex, const float *opacity, void *tplate_half,
+                                       void *stream);
 /* Frame-broadcast form of the same hand-off: ONE decoder output (tex [1,3*B,S,S], opacity [1,B,S,S]) shared by F frames,
  * frame f scaled by gain[f] in all four channels:  tplate [F, nh*nh, B,B,B, 4] = gain[f] * assemble(tex, opacity).
  * (User: the stand-in decoder of the train leg, ava-256_amd/trainloop.py; the reference's decoders emit per-frame outputs

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 15
     assert b"bad argument" in lib.mvp_error_string(-1)
     assert lib.mvp_error_string(0) == b"ok"
 
@@ -48,6 +48,33 @@ def test_code_object_is_gfx950_only():
     assert b"gfx950" in blob
     for other in (b"gfx90a", b"gfx942", b"sm_70", b"sm_80"):
         assert other not in blob
+
+
+def test_half_render_entry_points_validate_arguments(lib):
+    """mvp_march_render_half / mvp_template_to_half / mvp_template_assemble_forward_half (include/mvp_abi.h): forward only,
+    8^3 slabs, one of the two ray forms, aligned pointers -- all decided before any device work."""
+    buf = (ctypes.c_float * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    n = None
+    # N,H,W,K | raypos,raydir,tminmax | campos,camrot,focal,princpt,pixelcoords | volradius,stepsize |
+    # nodeaabb,primpos,primrot,primscale | TD,TH,TW | tplate_half,rayrgba | fadescale,fadeexp | diag,stream
+    a = [1, 1, 1, 1, p16, p16, p16, n, n, n, n, n, 1.0, 0.1, p16, p16, p16, p16, 8, 8, 8, p16, p16, 8.0, 8.0, n, n]
+    bad = list(a); bad[21] = None
+    assert lib.mvp_march_render_half(*bad) == -1            # no slab pointer
+    bad = list(a); bad[21] = p16 + 8
+    assert lib.mvp_march_render_half(*bad) == -1            # misaligned slabs
+    bad = list(a); bad[18] = 4
+    assert lib.mvp_march_render_half(*bad) == -2            # 8^3 slabs only
+    bad = list(a); bad[7] = p16
+    assert lib.mvp_march_render_half(*bad) == -1            # ray tensors AND cameras
+    bad = list(a); bad[0] = 0
+    assert lib.mvp_march_render_half(*bad) == 0             # empty batch
+    assert lib.mvp_template_to_half(-2, p16, p16, n) == -1
+    assert lib.mvp_template_to_half(3, p16, p16, n) == -1   # odd voxel count
+    assert lib.mvp_template_to_half(0, n, n, n) == 0
+    assert lib.mvp_template_to_half(2, n, p16, n) == -1
+    assert lib.mvp_template_assemble_forward_half(1, 2, 8, n, n, n, n) == -1
+    assert lib.mvp_template_assemble_forward_half(0, 2, 8, n, n, n, n) == 0
 
 
 def test_argument_validation_happens_before_any_device_work(lib):
