@@ -67,6 +67,12 @@ def algorithmic_bytes(N, H, W, K, V=512):
     return fwd, bwd
 
 
+def render_bytes(N, H, W, K, V=512, voxel_bytes=16):
+    """Algorithmic bytes of one no-grad render with the rays made inside the march (no ray tensors, rgba out only):
+    16 B per ray written, every slab voxel (16 B fp32 RGBA, 8 B fp16 RGBA) and pose record read once, the node boxes once."""
+    return 16 * N * H * W + N * K * (V * voxel_bytes + 60) + 24 * N * (2 * K - 1)
+
+
 def cpu_baseline(N, H, W, K, slab, budget_s=20.0, cams=1):
     """Time the fp32 CPU port (oracle/, OpenMP over rays) on a bounded sample of the same workload (`cams` cameras of it per
     pass)."""
@@ -209,6 +215,22 @@ def make_march_step_gpu(args, rank, world, dev):
                                                 volradius, stepsize, (s["primpos"], s["primrot"], s["primscale"]),
                                                 s["template"])
 
+    half = {}
+
+    def render_half():  # the opt-in render path over fp16 slabs (ava-256_amd/halfslab.py); conversion outside the timing
+        from ava256_amd import halfslab
+        if "t" not in half:
+            with torch.no_grad():
+                half["t"] = halfslab.template_to_half(s["template"])
+        return halfslab.render_half_from_cameras(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"],
+                                                 volradius, stepsize, (s["primpos"], s["primrot"], s["primscale"]),
+                                                 half["t"])
+
+    def to_half():
+        from ava256_amd import halfslab
+        with torch.no_grad():
+            return halfslab.template_to_half(s["template"])
+
     def hit_packets():  # 8x8 ray packets with a non-empty hit list (kernel diagnostics of one untimed forward)
         from ava256_amd import _hooks
         diag = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -221,7 +243,7 @@ def make_march_step_gpu(args, rank, world, dev):
             _hooks.set_diag_buffer(None)
 
     return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render,
-                  "fused_step": fused_step, "hit_packets_fn": hit_packets}
+                  "fused_step": fused_step, "hit_packets_fn": hit_packets, "render_half": render_half, "to_half": to_half}
 
 
 def kernel_averages(events):
@@ -229,6 +251,101 @@ def kernel_averages(events):
     for name, a, b in events:
         kt.setdefault(name, []).append(a.elapsed_time(b))
     return {k: sum(v) / len(v) for k, v in kt.items()}
+
+
+def time_calls(fn, dev, reps=5, warm=2):
+    """Average wall time (ms, device events on the current stream) of `reps` calls after `warm` untimed ones."""
+    for _ in range(warm):
+        fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    return ev0.elapsed_time(ev1) / reps
+
+
+def roofline_of(kavg, n_local, H, W, K, slab):
+    """Both march kernels of one workload against the HBM peak: algorithmic bytes per launch / HIP-event launch time."""
+    bf, bb = algorithmic_bytes(n_local, H, W, K, slab ** 3)
+    out = {}
+    for name, nbytes in (("march_forward", bf), ("march_backward", bb)):
+        ms = kavg.get(name)
+        if ms:
+            ach = nbytes / (ms * 1e-3) / 1e9
+            out[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "traffic": None}
+    return out
+
+
+def march_leg(args, rank, world, dev, workload, alpha_gain, steps=10, warmup=3):
+    """One more march workload on this rank, timed like the headline (same step through the operator API, HIP events per
+    launch): SURVEY.md 8(d)'s secondary runs -- C3 / C4 at their per-GPU batch, and the "trained-like" scene (opacity x 40:
+    about half the rays saturate, early termination primaccum.h:63-79, mvpraymarch_subset_kernel.h:76-97)."""
+    from ava256_amd import _hooks as mm
+    a = argparse.Namespace(**vars(args))
+    a.workload, a.alpha_gain, a.cams, a.scaling = workload, alpha_gain, None, "weak"
+    step, info = make_march_step_gpu(a, rank, world, dev)
+    for _ in range(warmup):
+        step()
+    events = []
+    mm.set_event_sink(events)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        out = step()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    mm.set_event_sink(None)
+    ms = ev0.elapsed_time(ev1) / steps
+    kavg = kernel_averages(events)
+    N, H, W, K, slab = info["n_local"], info["H"], info["W"], info["K"], info["slab"]
+    res = {"workload": "%s: %d cams/GPU, %dx%d, K=%d, alpha_gain %g" % (workload, N, H, W, K, alpha_gain),
+           "ms_per_step": ms, "rays_per_s": N * H * W / (ms * 1e-3), "steps": steps, "kernel_ms": kavg,
+           "saturated_ray_fraction": float((out.detach()[..., 3] >= 1.0 - 1e-6).float().mean()),
+           "roofline": roofline_of(kavg, N, H, W, K, slab)}
+    del step, info, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def collective_identity(dist, dev, world):
+    """What the first multi-GPU record should answer from the line itself: did the process group
+    see N ranks, which device is each rank on, and what bus bandwidth does ONE flat all-reduce of ava-256's gradient size
+    (46.87 M fp32 parameters = 187.5 MB, ddp-train.py:312: DDP over the whole model) reach: busbw = 2 (n-1)/n * bytes / t."""
+    name, bus = "cpu", None
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        name = pr.name
+        bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    me = {"rank": dist.get_rank(), "device": str(dev), "name": name, "pci": bus, "pid": os.getpid()}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    numel = 46_870_000 if dev.type == "cuda" else 1 << 18      # (the CPU test keeps it small)
+    buf = torch.ones(numel, device=dev, dtype=torch.float32)
+    reps = 10 if dev.type == "cuda" else 2
+    for _ in range(2):
+        dist.all_reduce(buf)
+    buf.fill_(1.0)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t = torch.tensor([(time.perf_counter() - t0) / reps], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sec = float(t.item())
+    nbytes = numel * 4
+    ok = bool(abs(float(buf[0].item()) - float(world) ** reps) <= 1e-3 * float(world) ** reps)
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+            "allreduce_bytes": nbytes, "allreduce_ms": sec * 1e3, "allreduce_algbw_gbs": nbytes / sec / 1e9,
+            "allreduce_busbw_gbs": 2.0 * (world - 1) / max(world, 1) * nbytes / sec / 1e9, "allreduce_sums_ok": ok,
+            "what": "one flat fp32 all_reduce of %d elements (ava-256's 187.5 MB gradient set when on GPUs), %d timed "
+                    "repetitions, MAX over ranks; busbw = 2 (n-1)/n * bytes / t" % (numel, reps)}
 
 
 def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None, config=None, graph=False):
@@ -381,6 +498,9 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     ap.add_argument("--no-train", action="store_true", help="skip the train leg (profiling runs of the march kernels)")
     ap.add_argument("--no-render", action="store_true", help="skip the no-grad render timing (profiling runs: keeps the "
                                                              "per-kernel averages those of the training-path launches)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the secondary march workloads (saturated scene, C3, C4)")
+    ap.add_argument("--no-collective-check", action="store_true",
+                    help="N > 1: skip the timed flat all-reduce / rank identities (`collectives` object)")
     ap.add_argument("--dist-smoke", action="store_true",
                     help="with ONE rank: still create the process group and wrap the train model in DDP, so that the "
                          "collectives of the N > 1 path run through RCCL on a single GPU (a test of the plumbing, not a "
@@ -446,30 +566,25 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     else:
         elapsed = run_timed(step, args.steps, args.warmup, dist, dev)
     kavg = kernel_averages(events)
-    render_ms = None
+    render_ms = render_half_ms = to_half_ms = None
     if gpu and "render" in info and not args.no_render:  # the forward alone as a renderer would call it (extra field, not the contract value)
-        for _ in range(2):
-            info["render"]()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(5):
-            info["render"]()
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        render_ms = ev0.elapsed_time(ev1) / 5
+        render_ms = time_calls(info["render"], dev)
+    if gpu and "render_half" in info and not args.no_render:  # ... and over fp16 slabs (opt-in; never the contract value)
+        with torch.no_grad():
+            render_half_ms = time_calls(info["render_half"], dev)
+        to_half_ms = time_calls(info["to_half"], dev)
     if gpu and "hit_packets_fn" in info and not args.no_render:
         info["hit_packets"] = info["hit_packets_fn"]()
     fused_ms = None
     if gpu and "fused_step" in info and not args.no_render:  # the training step with row N1's fusion (extra field as well)
-        for _ in range(2):
-            info["fused_step"]()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(5):
-            info["fused_step"]()
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        fused_ms = ev0.elapsed_time(ev1) / 5
+        fused_ms = time_calls(info["fused_step"], dev)
+    # SURVEY.md 8(d)'s secondary march runs, this rank: the trained-like scene and the other single-GPU configurations
+    legs = {}
+    if gpu and not args.no_render and not args.no_workloads and args.workload == "C2":
+        legs["saturated"] = march_leg(args, rank, world, dev, "C2", 40.0)
+        legs["C3"] = march_leg(args, rank, world, dev, "C3", 1.0, steps=20)
+        legs["C4"] = march_leg(args, rank, world, dev, "C4", 1.0, steps=20)
+    ident = collective_identity(dist, dev, world) if (dist is not None and not args.no_collective_check) else None
 
     # rays of all ranks per step: every rank contributes its own shard (gathered, so that uneven strong-scaling
     # shards are counted exactly)
@@ -554,6 +669,22 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             if render_ms is not None:
                 out["render"] = {"what": "no-grad forward with rays made inside the march (mvp_march_forward_cams), this rank",
                                  "ms": render_ms, "rays_per_s": info["n_local"] * H * W / (render_ms * 1e-3)}
+            if render_half_ms is not None:
+                hb = render_bytes(info["n_local"], H, W, K, slab ** 3, 8)
+                fb = render_bytes(info["n_local"], H, W, K, slab ** 3, 16)
+                out["render_fp16"] = {
+                    "what": "OPT-IN render path over fp16 RGBA slabs (mvp_march_render_half: 4 x 16-byte gathers per sample, fp32 "
+                            "weights / interpolation / compositing), rays made inside the march, this rank; parity: kernel vs the "
+                            "float64 oracle on the same rounded slabs within 2e-4 (tests/test_gpu_half.py); NOT the headline",
+                    "dtype": "f16 slab storage, f32 arithmetic", "ms": render_half_ms,
+                    "rays_per_s": info["n_local"] * H * W / (render_half_ms * 1e-3),
+                    "speedup_vs_render_f32": (render_ms / render_half_ms) if render_ms else None,
+                    "template_to_half_ms": to_half_ms,
+                    "roofline": {"bound": "hbm", "achieved": hb / (render_half_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": hb / (render_half_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": hb, "traffic": None},
+                    "render_f32_roofline": {"achieved": fb / (render_ms * 1e-3) / 1e9 if render_ms else None,
+                                            "algorithmic_bytes_per_launch": fb}}
             if fused_ms is not None:
                 out["fused_rays_step"] = {"what": "the same training step with the rays made inside the forward march "
                                                   "(mvpraymarch_from_cameras + backward: no raydirs launch), this rank",
@@ -577,6 +708,11 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                     "kernels": {k: dict(v, wave_insts_per_hit_packet=(v["wave_insts"] / hp) if hp else None)
                                 for k, v in valu.items()},
                     "hit_packets_per_launch": hp}
+        if legs:
+            out["saturated"] = legs.pop("saturated")
+            out["workloads"] = legs
+        if ident is not None:
+            out["collectives"] = ident
         if train is not None:
             out["train"] = train
         if gpu and world == 1 and not args.no_cpu_baseline:

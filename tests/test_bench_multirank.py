@@ -80,6 +80,15 @@ def test_bench_two_ranks_weak_scaling(tmp_path):
     rays = 2 * 5 * 16 * 16
     assert abs(j["value"] - rays * j["steps"] / (j["ms_per_step"] * 1e-3 * j["steps"])) <= 1e-6 * j["value"]
     assert "cpu_baseline" not in j and "train" not in j        # GPU-only legs
+    # what the first multi-GPU record has to answer from the line itself: did the process group see
+    # N ranks, on which devices, and the bus bandwidth of one flat gradient-sized all-reduce
+    c = j["collectives"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["allreduce_sums_ok"] is True
+    assert [r["rank"] for r in c["ranks"]] == [0, 1] and len({r["pid"] for r in c["ranks"]}) == 2
+    assert all(set(r) >= {"rank", "device", "name", "pci", "pid"} for r in c["ranks"])
+    assert c["allreduce_bytes"] > 0 and c["allreduce_ms"] > 0
+    assert abs(c["allreduce_busbw_gbs"] - 2.0 * (2 - 1) / 2 * c["allreduce_bytes"] / (c["allreduce_ms"] * 1e-3) / 1e9) <= 1e-6 * c["allreduce_busbw_gbs"]
+    assert abs(c["allreduce_busbw_gbs"] - c["allreduce_algbw_gbs"]) <= 1e-9 + 1e-6 * c["allreduce_algbw_gbs"]   # n = 2: 2 (n-1)/n = 1
 
 
 def test_bench_two_ranks_strong_scaling(tmp_path):
@@ -184,6 +193,10 @@ def test_collectives_of_the_multi_gpu_path_run_through_rccl_on_one_gpu(mode):
     assert len(lines) == 1, res.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["ms_per_step"] > 0
+    if mode == "march":   # the flat gradient-sized all-reduce and the rank identities, through RCCL (one rank: busbw = 0)
+        c = j["collectives"]
+        assert c["world_size"] == 1 and c["backend"] == "nccl" and c["allreduce_sums_ok"] is True
+        assert c["allreduce_bytes"] == 46_870_000 * 4 and c["allreduce_ms"] > 0 and c["ranks"][0]["pci"] is not None
     if mode == "train":
         t = j["train"]
         assert t["allreduce_mb"] > 0 and t["final_loss"] == t["final_loss"]      # DDP was on; the loss is finite
