@@ -8,6 +8,7 @@ events = None  # list collecting (name, start_event, end_event) per C-ABI launch
 keep_raysat = False                 # tests: keep the last forward's raysat tensor in `last_raysat`
 last_raysat = None
 last_pl_count = None                # ... and its forward->backward hand-off counters ([N*K] counts, then flags, bounds)
+last_flags_index = 0                # index of the flags word in it (N*K)
 
 
 class patched_handoff:

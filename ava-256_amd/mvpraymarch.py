@@ -55,6 +55,9 @@ def wanted_from_histogram(words):
     return mx if mx <= 2 * max(q, 16) else 2 * max(q, 16)
 
 
+# Written by forwards only (host thread; the backward on the autograd thread never touches it): single dict operations
+# under the GIL, and a lost update costs one call a stale capacity, never a wrong result (lists over capacity are marched by
+# the ray-centric kernel).
 _LIST_DEMAND = {}  # (device index, H, W, K) -> _ListDemand
 _LIST_BYTES_MIN = 64 << 20  # the lists of a call may take this much ...
 _LIST_BYTES_PER_PRIM = 2048  # ... or this much per primitive (a quarter of an 8^3 slab), whichever is more
@@ -229,6 +232,7 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
     if _hooks.keep_raysat:
         _hooks.last_raysat = raysat
         _hooks.last_pl_count = pl_count
+        _hooks.last_flags_index = N * K     # pl_count[N*K] = the flags word (include/mvp_abi.h)
     # (camera form in grad mode: raypos / raydir / tminmax are the tensors the forward march has just written)
     ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
                           pl_count, pl_list, warp)

@@ -37,6 +37,9 @@ _op = importlib.import_module(__package__ + ".mvpraymarch")  # (the package re-e
 # bounded in BYTES: a caller that keeps grad-mode images alive (logging, evaluation without no_grad) would otherwise keep
 # every forward's hand-off buffers with them.  Over the budget the oldest entries go; a backward that finds none takes the
 # ray-centric kernel, which needs no hand-off (correct, slow).
+# Threads: the forward shim (host thread) inserts and evicts, the backward shim (autograd thread) only reads with .get(); each
+# is a single dict operation under the GIL, and an entry evicted between the two costs a backward the fast path, not its
+# correctness (it then takes the ray-centric kernel).
 _HANDOFF = {}
 HANDOFF_BYTES_MAX = 4 << 30
 
@@ -67,34 +70,57 @@ def _handoff_take(rayrgba, shape):
     return ent[1:]
 
 
-STRICT_ORDER_CHECK = False  # True: validate `sortedobjid` with a host synchronisation inside the call (debugging)
-_ORDER_PENDING = []   # [(event, pinned word)]: device-side checks of earlier calls not yet looked at
-_ARANGE = {}          # (device index, K, dtype) -> arange(K)
+STRICT_ORDER_CHECK = False   # True: every call validates `sortedobjid` with a host synchronisation inside the call
+STRICT_FIRST_CALLS = 8       # ... as the first calls of a process do anyway, and every call that renders without gradients
+_ORDER_PENDING = []          # [(event, pinned word, weakref(tensor), version)]: device-side checks not yet looked at
+_ORDER_CALLS = [0]           # content checks enqueued so far
+_ARANGE = {}                 # (device index, K, dtype) -> arange(K)
+_BAD_ORDER = ("sortedobjid of %s raymarch call is not the fixed identity order (its results are in the wrong composition "
+              "order): only usebvh='fixedorder' without randomorder is supported")
 
 
-def _poll_order_checks(wait=False):
-    """Look at the checks of earlier calls that have completed (all of them with wait=True); raise for a bad order."""
-    keep = []
-    for ev, word in _ORDER_PENDING:
+def _poll_order_checks(wait=False, current=False):
+    """Look at the device-side verdicts that have arrived (all of them with wait=True).  A tensor is marked as checked only
+    HERE, once its verdict has been read as "identity" -- never before the verdict is known, so a caller that catches the
+    error and hands the same bad tensor in again is refused again.  Raises for a bad order; the other pending verdicts stay
+    queued.  Called from the forward and backward shims (host thread and autograd thread): the list is swapped, not edited in
+    place, and a verdict looked at twice is harmless."""
+    pending, bad, keep = list(_ORDER_PENDING), False, []
+    for item in pending:
+        ev, word, ref, ver = item
         if wait:
             ev.synchronize()
         if ev.query():
             if int(word[0]) != 0:
-                _ORDER_PENDING[:] = []
-                raise NotImplementedError(
-                    "sortedobjid of an EARLIER raymarch call was not the fixed identity order (its results are in the "
-                    "wrong composition order): only usebvh='fixedorder' without randomorder is supported")
+                bad = True
+            else:
+                t = ref()
+                if t is not None and t._version == ver:
+                    t._mvp_identity = ver
         else:
-            keep.append((ev, word))
-    _ORDER_PENDING[:] = keep
+            keep.append(item)
+    _ORDER_PENDING[:] = keep + [i for i in _ORDER_PENDING if i not in pending]
+    if bad:
+        raise NotImplementedError(_BAD_ORDER % ("this" if current and wait else "an EARLIER"))
 
 
-def _identity_order(sortedobjid, K):
+def flush_order_checks():
+    """Public: wait for every outstanding `sortedobjid` verdict and raise if one of them was a wrong order.  A caller that
+    renders once and reads the image back (evaluation) may call this before trusting the result of a deferred check; the
+    shim itself checks INSIDE the call whenever gradients are off, and for the first STRICT_FIRST_CALLS calls."""
+    _poll_order_checks(wait=True)
+
+
+def _identity_order(sortedobjid, K, strict=False):
     """usebvh='fixedorder' hands arange(K) per image (mvpraymarch.py:45); any other order (randomorder=True, the LBVH
-    path) would silently render in the wrong composition order here.  The reference's glue builds a NEW sortedobjid on
-    every forward, so this runs on every call of the drop-in path and must not block the host: shape errors raise at once,
-    the CONTENT is compared on the device, the one-word verdict travels to pinned memory behind an event and is looked at by
-    the next calls (the error is then raised one call late; `STRICT_ORDER_CHECK = True` waits for it inside the call).
+    path) would silently render in the wrong composition order here.  Shape errors raise at once.  The CONTENT is compared
+    on the device; WHEN the one-word verdict is read depends on who is calling:
+      * a call without gradients (a render / evaluation: possibly the only call there is), the first STRICT_FIRST_CALLS
+        calls of the process, and everything under STRICT_ORDER_CHECK wait for it inside the call -- the offending call
+        itself fails, before its image can be used;
+      * a training step (the reference's glue builds a NEW sortedobjid on every forward, so the check runs on every call
+        and must not block the host) leaves the verdict behind an event; the backward of the same step and the next calls
+        look at it.  An order policy is a constant of a run, so a wrong one has failed within the strict first calls.
     Nothing is enqueued while a stream is being captured."""
     if sortedobjid is None:
         return
@@ -112,10 +138,10 @@ def _identity_order(sortedobjid, K):
     word.copy_((sortedobjid != ar[None]).any().to(torch.int32).reshape(1), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    _ORDER_PENDING.append((ev, word))
-    sortedobjid._mvp_identity = sortedobjid._version
-    if STRICT_ORDER_CHECK or len(_ORDER_PENDING) > 64:
-        _poll_order_checks(wait=True)
+    _ORDER_PENDING.append((ev, word, weakref.ref(sortedobjid), sortedobjid._version))
+    _ORDER_CALLS[0] += 1
+    if strict or STRICT_ORDER_CHECK or _ORDER_CALLS[0] <= STRICT_FIRST_CALLS or len(_ORDER_PENDING) > 64:
+        _poll_order_checks(wait=True, current=True)
 
 
 def compute_morton(*args):
@@ -158,7 +184,7 @@ def raymarch_forward(raypos, raydir, stepsize, tminmax, sortedobjid, nodechildre
     if algo == 0:
         warp = None
     WD, WH, WW = (warp.size(2), warp.size(3), warp.size(4)) if warp is not None else (0, 0, 0)
-    _identity_order(sortedobjid, K)
+    _identity_order(sortedobjid, K, strict=raysat is None)   # (no raysat = no gradients: mvpraymarch.py:147-152)
     raypos, raydir, tminmax, template = aligned(raypos), aligned(raydir), aligned(tminmax), aligned(template)
     if warp is not None:
         warp = aligned(require_device_f32("warp", warp))

@@ -137,15 +137,20 @@ class _WideLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        gx = None
+        g = g.contiguous()   # (an expanded / transposed upstream gradient is a legal autograd output)
+        gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             M = weight.shape[0]
             if M % 1024 == 0 and M > 1024:   # split-K by hand: [S, B, 1024] x [S, 1024, C] -> sum over S
                 S = M // 1024
-                gx = torch.bmm(g.view(g.shape[0], S, 1024).transpose(0, 1), weight.view(S, 1024, -1)).sum(0)
+                gx = torch.bmm(g.view(g.shape[0], S, 1024).transpose(0, 1), weight.reshape(S, 1024, -1)).sum(0)
             else:
                 gx = g @ weight
-        return gx, g.t() @ x, g.sum(0)
+        if ctx.needs_input_grad[1]:
+            gw = g.t() @ x
+        if ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
 
 
 class CodeEncoderStandIn(nn.Module):
@@ -556,6 +561,7 @@ class Trainer:
         self.last_grad_norm = None
         self._graphs, self._eager_seen, self._graph_warmup = {}, {}, int(graph_warmup)
         self.graph_replays = 0
+        self.graph_check_every, self.graph_recaptures = 64, 0   # replays between looks at the list-overflow flag; graphs dropped
 
     @classmethod
     def from_config(cls, model, cfg, **kw):
@@ -650,10 +656,22 @@ class Trainer:
             st = self._graphs[key] = self._capture(batch, schedule)
         for k, t in st["in"].items():
             src = batch[k]
-            if src.data_ptr() != t.data_ptr():
+            if torch.is_tensor(t) and src.data_ptr() != t.data_ptr():
                 t.copy_(src)
         st["graph"].replay()
         self.graph_replays += 1
+        st["replays"] += 1
+        if st["handoff"] is not None and st["replays"] % self.graph_check_every == 0:
+            # The graph froze the march's primitive-list capacity of the moment it was captured (the operators skip their
+            # demand feedback while capturing and on replay).  If primitive footprints have grown since, primitives over that
+            # capacity sit on the slow ray-centric backward for the rest of the graph's life: look at the forward's overflow
+            # flag now and then (one 4-byte read-back) and, when it is raised, drop the graph -- the next iterations run eagerly
+            # (their feedback re-sizes the lists) and a new graph is captured.
+            pl_count, nk = st["handoff"]
+            if int(pl_count[nk].item()) & 1:          # kFlagListOverflow (csrc/march_common.h)
+                del self._graphs[key]
+                self._eager_seen[key] = 0
+                self.graph_recaptures += 1
         self.last_grad_norm = st["norm"]
         self._advance()
         return st["loss"], st["parts"]
@@ -663,15 +681,25 @@ class Trainer:
         intermediate -- gradients included -- lives in the graph's private pool and is reused by each replay.  The operators
         of this package skip their host-side bookkeeping while a stream is being captured (list-capacity feedback, index
         checks), so the capacities of this moment are the graph's."""
-        static_in = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        from . import _hooks
+        # (non-tensor entries -- a (W, H) pixelcoords tuple -- are part of the batch the iteration reads: passed through)
+        static_in = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         torch.cuda.synchronize()
         self.optim.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss, parts = self._iteration(static_in, schedule)
-            norm = self.last_grad_norm
+        keep = _hooks.keep_raysat
+        _hooks.keep_raysat, _hooks.last_pl_count = True, None
+        try:
+            with torch.cuda.graph(g):
+                loss, parts = self._iteration(static_in, schedule)
+                norm = self.last_grad_norm
+            handoff = None
+            if _hooks.last_pl_count is not None:   # the captured forward's counters + flags word (a tensor of the graph's pool)
+                handoff = (_hooks.last_pl_count, _hooks.last_flags_index)
+        finally:
+            _hooks.keep_raysat, _hooks.last_raysat, _hooks.last_pl_count = keep, None, None
         # the capture itself ran nothing: the first replay is this iteration
-        return {"graph": g, "in": static_in, "loss": loss, "parts": parts, "norm": norm}
+        return {"graph": g, "in": static_in, "loss": loss, "parts": parts, "norm": norm, "handoff": handoff, "replays": 0}
 
 
 @torch.no_grad()

@@ -141,11 +141,12 @@ def test_handoff_buffers_are_bounded_in_bytes():
 
 
 @pytest.mark.gpu
-def test_shim_order_check_without_a_host_synchronisation():
-    """raymarch_forward's sortedobjid must be the fixed identity order (mvpraymarch.py:45).  The reference's glue builds a
-    new tensor per forward, so the check runs per call and must not block: the verdict is computed on the device and read
-    by a LATER call.  Identity passes (every call); a permuted order raises -- at the next call, or inside the call with
-    STRICT_ORDER_CHECK; a wrong shape raises at once."""
+def test_shim_order_check():
+    """raymarch_forward's sortedobjid must be the fixed identity order (mvpraymarch.py:45).  Identity passes on every call.  A
+    permuted order fails INSIDE the offending call when gradients are off (a render may be the only call there is) and during
+    the first STRICT_FIRST_CALLS calls; in a training step past those the verdict is read without blocking -- by the same
+    step's backward or the next call -- and a tensor is never marked good before its verdict says so: handing the same bad
+    tensor in again is refused again.  A wrong shape raises at once."""
     import extensions.mvpraymarch.mvpraymarchlib as lib
     from ava256_amd import native_shim as ns
     from ava256_amd.scene import make_scene
@@ -158,28 +159,41 @@ def test_shim_order_check_without_a_host_synchronisation():
     nodeaabb = torch.empty((N, 2 * K - 1, 2, 3), device=dev)
     lib.compute_aabb(s["primpos"], s["primrot"], s["primscale"], None, nodechildren, None, nodeaabb, 0)
 
-    def fwd(order):
+    def fwd(order, grad=False):
         rgba = torch.empty((N, H, W, 4), device=dev)
+        raysat = torch.empty((N, H, W, 3), device=dev) if grad else None
         lib.raymarch_forward(rp, rd, s["stepsize"], tm, order, nodechildren, nodeaabb, s["primpos"], s["primrot"],
-                             s["primscale"], s["template"], None, rgba, None, None, 0, False, 512, True, True)
+                             s["primscale"], s["template"], None, rgba, raysat, None, 0, False, 512, True, True)
         return rgba
 
-    ns._poll_order_checks(wait=True)
+    ns.flush_order_checks()
     ident = lambda: (torch.arange(N * K, dtype=torch.int32, device=dev) % K).view(N, K)
-    for _ in range(3):
-        fwd(ident())                                   # a fresh tensor per call, like the reference's build_accel
-    ns._poll_order_checks(wait=True)                   # nothing to report
     perm = ident().flip(1).contiguous()
-    fwd(perm)                                          # enqueued, not yet judged
+    # (1) without gradients the offending call itself fails, every time, also past the strict first calls
+    ns._ORDER_CALLS[0] = ns.STRICT_FIRST_CALLS + 100
+    for _ in range(2):
+        with pytest.raises(NotImplementedError, match="this raymarch call"):
+            fwd(perm)
+    assert getattr(perm, "_mvp_identity", None) is None          # never marked good
+    good = ident()
+    fwd(good)
+    assert good._mvp_identity == good._version                   # marked once its verdict was read
+    # (2) a training step past the strict first calls does not block: the verdict is read later ...
+    for _ in range(3):
+        fwd(ident(), grad=True)
+    ns.flush_order_checks()                                      # nothing to report
+    bad2 = ident().flip(1).contiguous()
+    fwd(bad2, grad=True)                                         # enqueued, not yet judged
     torch.cuda.synchronize()
+    with pytest.raises(NotImplementedError, match="EARLIER"):
+        fwd(ident(), grad=True)                                  # ... the next call reports it
     with pytest.raises(NotImplementedError):
-        fwd(ident())                                   # ... the next call reports it
-    ns._poll_order_checks(wait=True)                   # (and the report is not repeated)
-    ns.STRICT_ORDER_CHECK = True
-    try:
-        with pytest.raises(NotImplementedError):
-            fwd(ident().flip(1).contiguous())
-    finally:
-        ns.STRICT_ORDER_CHECK = False
+        fwd(bad2, grad=True); torch.cuda.synchronize(); ns.flush_order_checks()   # the same bad tensor again: refused again
+    ns.flush_order_checks()                                      # (and a report is not repeated)
+    # (3) the first calls of a process are strict in grad mode too
+    ns._ORDER_CALLS[0] = 0
+    with pytest.raises(NotImplementedError, match="this raymarch call"):
+        fwd(ident().flip(1).contiguous(), grad=True)
+    ns._ORDER_CALLS[0] = ns.STRICT_FIRST_CALLS + 100
     with pytest.raises(NotImplementedError):
         fwd(ident()[:, : K // 2].contiguous())
