@@ -39,16 +39,15 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# The reference's own code timed on CPU.  Its Python may not travel to the GPU box, so these are the measurements taken
-# where it is mounted (the build container: 8 cores, torch 2.10 CPU; BASELINE.md section 2, re-measurable with
-# tests/golden/gen_golden.py) -- carried beside the live `cpu_baseline` (this build's CPU port on the GPU box's cores).
-REFERENCE_CPU = {
-    "where": "build container, 8 CPU cores, torch 2.10.0 CPU (BASELINE.md section 2); NOT the GPU box's host",
-    "dense_raymarch_oracle": {"scene": "mvpraymarch.py gradcheck: N=2, 65x65, K=64, 32^3 slabs, fp32",
-                              "fwd_s": 9.12, "bwd_s": 13.02, "fwd_rays_per_s": 927.0, "fwd_bwd_rays_per_s": 382.0},
-    "autoencoder": {"model": "reference Autoencoder, K=16384, 46.9 M params, batch 1, 128x128, raymarch stubbed",
-                    "fwd_s": 4.6, "bwd_s": 1.5},
-}
+# The reference's own code timed on CPU.  Its Python may not travel to the GPU box, so these are measurements taken where it
+# is mounted (the build container) by tools/measure_reference_cpu.py, recorded with the commit, date and core count in
+# profiles/reference_cpu.json -- carried beside the live `cpu_baseline` (this build's CPU port on the GPU box's cores).
+def reference_cpu():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "reference_cpu.json")))
+    except Exception as e:
+        return {"error": "profiles/reference_cpu.json not readable: %s" % e}
+
 
 WORKLOADS = {
     # name: (N cams per GPU, H, W, K, slab)
@@ -721,7 +720,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             # second CPU timing: all four cameras, a few seconds
             c1 = WORKLOADS["C1"]
             out["cpu_baseline"]["C1"] = cpu_baseline(c1[0], c1[1], c1[2], c1[3], c1[4], budget_s=4.0, cams=c1[0])
-            out["reference_cpu"] = REFERENCE_CPU
+            out["reference_cpu"] = reference_cpu()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

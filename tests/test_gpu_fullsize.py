@@ -85,7 +85,7 @@ def test_config_sizes_against_oracle(cfg, oracle64, oracle32):
     handoff = _hooks.last_pl_count
     _hooks.keep_raysat = False
     _hooks.last_raysat = _hooks.last_pl_count = None
-    fragile = FragileRays(ref_sat, st["margin"], gout)   # only rays the ORACLE calls borderline may be masked
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])   # only rays the ORACLE calls borderline may be masked
     gout = fragile(hip_sat)
     fr = fragile.mask
     rgba.backward(torch.as_tensor(gout, dtype=torch.float32, device="cuda"))
@@ -155,7 +155,7 @@ def test_c2_camera_with_heavy_tailed_upstream_gradients(style, oracle64):
     hip_sat, handoff = npf(_hooks.last_raysat), _hooks.last_pl_count
     _hooks.keep_raysat = False
     _hooks.last_raysat = _hooks.last_pl_count = None
-    fragile = FragileRays(ref_sat, st["margin"], gout, edge=st["edge"])
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"], edge=st["edge"])
     g2 = fragile(hip_sat)
     rgba.backward(torch.as_tensor(g2, dtype=torch.float32, device="cuda"))
     torch.cuda.synchronize()
@@ -210,7 +210,7 @@ def test_smooth_templates_tight_pose_gradients(cfg, oracle64):
     rp_d, rd_d, tm_d = ops.compute_raydirs(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"])
     t = {k: d[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
     rgba = ops.mvpraymarch(rp_d, rd_d, d["stepsize"], tm_d, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     gout = fragile(npf(_hooks.last_raysat))
     _hooks.keep_raysat = False
     _hooks.last_raysat = None

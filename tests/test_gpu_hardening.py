@@ -88,7 +88,7 @@ def test_heavy_tailed_upstream_gradient(ops, oracle64, mode):
     outl = rng.random(size=ref_rgba.shape[:3]) < 1e-3
     assert outl.sum() >= 5
     gout[outl] *= 1.0e4
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
     rgp, rgr, rgs, rgt = oracle64.march_backward(*a, ref_sat, fragile.masked())
     got = grads["template"].reshape(K, -1)
@@ -126,7 +126,7 @@ def test_signed_opacity(ops, oracle64, mode):
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
     assert ref_rgba[..., 3].min() < -0.2 and st["rays_saturated"] > 50       # alpha really goes negative, rays saturate
     gout = np.random.default_rng(6).normal(size=ref_rgba.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout, max_frac=0.01, min_allowed=4)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"], max_frac=0.01, min_allowed=4)
     rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
     fr = fragile.mask
     err = np.abs(rgba - ref_rgba).max(-1)
@@ -154,7 +154,7 @@ def test_warp_field_with_signed_opacity(ops, oracle64, mode):
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, warp=warp, ray_diagnostics=True)
     assert ref_rgba[..., 3].min() < -0.2 and st["rays_saturated"] > 50
     gout = np.random.default_rng(7).normal(size=ref_rgba.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout, max_frac=0.01, min_allowed=4)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"], max_frac=0.01, min_allowed=4)
     rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode, warp=warp)
     rgp, rgr, rgs, rgt, rgw = oracle64.march_backward(*a, ref_sat, fragile.masked(), warp=warp)
     _check_grads(grads, dict(template=rgt, primpos=rgp, primrot=rgr, primscale=rgs), "signed alpha + warp " + mode)
@@ -200,7 +200,7 @@ def test_block_to_image_mapping_with_eight_or_more_images(ops, oracle64, N, mode
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
     assert st["rays_hit"] > 0
     gout = np.random.default_rng(N).normal(size=ref_rgba.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
     fr = fragile.mask
     err = np.abs(rgba - ref_rgba).max(-1)
@@ -332,7 +332,7 @@ def test_list_capacity_follows_the_demand(ops, oracle64):
     a = (rp, rd, s["stepsize"], tm, s["primpos"].numpy(), s["primrot"].numpy(), s["primscale"].numpy(), s["template"].numpy())
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
     gout = np.random.default_rng(4).normal(size=ref_rgba.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     ref = dict(zip(("primpos", "primrot", "primscale", "template"), oracle64.march_backward(*a, ref_sat, gout)))
     seen = []
     for call in range(2):

@@ -143,7 +143,7 @@ def test_march_matches_oracle_on_synthetic_scenes(ops, oracle64, cfg, mode):
     rng = np.random.default_rng(3)
     gout = rng.normal(size=ref_rgba.shape)
     # rays the ORACLE calls borderline may saturate elsewhere in fp32 (helpers.FragileRays); anything else must agree
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile, mode=mode)
     assert diag["list_overflow"] == 0 and diag["frontier_overflow"] == 0
     assert diag["packets_hit"] > 0
@@ -177,7 +177,7 @@ def test_non_cubic_slabs_and_general_fade(ops, oracle64, shape, fadescale, fadee
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, fadescale=fadescale, fadeexp=fadeexp, ray_diagnostics=True)
     assert st["rays_hit"] > 0 and st["list_overflow"] == 0
     gout = rng.normal(size=ref_rgba.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, mode=mode)
     fr = fragile.mask
     g2 = fragile.masked()
@@ -251,7 +251,7 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, fadescale=fadescale, fadeexp=fadeexp, ray_diagnostics=True, warp=warp)
     if st["rays_hit"] == 0 or st["list_overflow"] > 0:
         pytest.skip("degenerate draw")
-    fragile = FragileRays(ref_sat, st["margin"], gout, max_frac=0.01, min_allowed=3, edge=st["edge"])
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"], max_frac=0.01, min_allowed=3, edge=st["edge"])
     rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, mode=mode, warp=warp)
     fr = fragile.mask
     g2 = fragile.masked()
@@ -362,7 +362,7 @@ def test_warp_sampler_matches_oracle_on_a_shell_scene(ops, oracle64, wshape, noi
          s["template"].numpy())
     ref_rgba, ref_sat, st = oracle64.march_forward(*a, warp=warp, fadescale=fadescale, fadeexp=fadeexp, ray_diagnostics=True)
     gout = np.random.default_rng(8).normal(size=ref_rgba.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, warp=warp, mode=mode)
     fr = fragile.mask
     g2 = fragile.masked()
@@ -451,7 +451,7 @@ def test_very_fine_steps_use_the_unpacked_path(ops, oracle64):
     ref, ref_sat, st = oracle64.march_forward(*a, ray_diagnostics=True)
     assert st["steps"] / max(1, st["rays_hit"]) > 65535     # more lattice steps per ray than the packed ranges hold
     gout = np.random.default_rng(2).normal(size=ref.shape)
-    fragile = FragileRays(ref_sat, st["margin"], gout)
+    fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"])
     rgba, grads, diag = _march(ops, *a, 8.0, 8.0, grad_out=fragile)
     g2 = fragile.masked()
     rg = dict(zip(("primpos", "primrot", "primscale", "template"), oracle64.march_backward(*a, ref_sat, g2)))
