@@ -9,7 +9,7 @@ namespace mvp {
 
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
-//   LDS: [V] float4 template slab | [4][Vp] int32 fixed-point gradient |
+//   LDS: [V] float4 template slab | [4][Vp] int32 fixed-point gradient (plain sampler: packed as [2][Vp] int64) |
 //        ray queue (kQueueCap x 8 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
@@ -27,7 +27,9 @@ namespace mvp {
 // per ACTIVE LANE (193 cycles per wave64 instruction, any address pattern) while ds_add_u32 takes 4.8 cycles per
 // wave instruction when conflict-free.  The 32 contributions of a sample are therefore accumulated in FIXED POINT with
 // integer LDS atomics, ONE int32 word per slab float (round 3; rounds 1-2 used a hi/lo pair of words = 64 atomics per
-// sample, and the LDS pipe was busy 82 % of the kernel):  acc += rn(value * s),  s = 0.999 * 2^31 / (n * B)  where
+// sample, and the LDS pipe was busy 82 % of the kernel) -- and since round 5 TWO such words per 64-bit atomic (16 ds_add_u64
+// per sample: word = hi * 2^32 + lo with signed lo, acc_read4; measured at the kernel's lane activity a ds_add_u64 costs 1.45 x
+// a ds_add_u32, tools/ubench/lds_pack64.hip; C2 5.76 -> 5.63 ms, C4 0.98 -> 0.94):  acc += rn(value * s),  s = 0.999 * 2^31 / (n * B)  where
 //   * n is the EXACT number of samples of the current round (counted while the rays are queued) and B bounds any single
 //     contribution of the round, so |sum| < 2^31: no overflow.  B = G_q * min(1, Amax * dt) for the colour channels:
 //     G_q = max |grad_rayrgba| over the ray PACKETS of the round's list entries (packetmax_kernel, one pass over the
@@ -123,6 +125,30 @@ __global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict
     }
 }
 
+// The four fixed-point sums of gradient cell gv.  PACKED (plain sampler): two 64-bit words, word = hi * 2^32 + lo with SIGNED
+// lo -- channels (r | g) in plane 0 and (b | a) in plane 1 -- so that a sample's scatter is 16 ds_add_u64 instead of 32
+// ds_add_u32: lo by sign extension, hi = (word - lo) >> 32, exact while |sum lo| < 2^31 (the per-round bound).
+template <bool PACKED>
+__device__ __forceinline__ void acc_read4(const int *s_acc, int Vp, int gv, int &a, int &b, int &c, int &d) {
+    if constexpr (PACKED) {
+        const long long *q = reinterpret_cast<const long long *>(s_acc);
+        const long long w0 = q[gv], w1 = q[Vp + gv];
+        a = (int)w0, b = (int)((w0 - (long long)a) >> 32);
+        c = (int)w1, d = (int)((w1 - (long long)c) >> 32);
+    } else {
+        a = s_acc[gv], b = s_acc[Vp + gv], c = s_acc[2 * Vp + gv], d = s_acc[3 * Vp + gv];
+    }
+}
+template <bool PACKED>
+__device__ __forceinline__ void acc_clear4(int *s_acc, int Vp, int gv) {
+    if constexpr (PACKED) {
+        long long *q = reinterpret_cast<long long *>(s_acc);
+        q[gv] = 0ll, q[Vp + gv] = 0ll;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_acc[c * Vp + gv] = 0;
+    }
+}
 __device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
 // float -> int, round to nearest (ties up): v_cvt_rpi_i32_f32.  (int)x truncates toward zero, a systematic shrink of
@@ -149,7 +175,9 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     const int gH = TW, gD = TH * TW + kGradPadZ;  // gradient-array strides (words); x stride 1
     const int Vp = TD * gD;
     float4 *s_T = smem4;
-    int *s_acc = reinterpret_cast<int *>(smem4 + V);  // [4][Vp], channel-planar fixed-point sums
+    // fixed-point sums: [4][Vp] int32, channel-planar (warp-field variant) -- or the same bytes as [2][Vp] int64, two channels
+    // per word: (r | g), (b | a) (plain sampler: acc_read4 / the scatter of the walk)
+    int *s_acc = reinterpret_cast<int *>(smem4 + V);
     uint2 *s_q = reinterpret_cast<uint2 *>(s_acc + 4 * Vp);  // (Vp is even: 8-byte aligned)
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
     uint32_t *s_qn = reinterpret_cast<uint32_t *>(s_red + 64);
@@ -350,17 +378,15 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;
             float4 g;
-            g.x = (float)s_acc[gv] * i_rgb;
-            g.y = (float)s_acc[Vp + gv] * i_rgb;
-            g.z = (float)s_acc[2 * Vp + gv] * i_rgb;
-            g.w = (float)s_acc[3 * Vp + gv] * i_a;
+            int ia_, ib_, ic_, id_;
+            acc_read4<!WARP>(s_acc, Vp, gv, ia_, ib_, ic_, id_);
+            g.x = (float)ia_ * i_rgb, g.y = (float)ib_ * i_rgb, g.z = (float)ic_ * i_rgb, g.w = (float)id_ * i_a;
             if (drained) {
                 const float4 o_ = gd[v];
                 g.x += o_.x, g.y += o_.y, g.z += o_.z, g.w += o_.w;
             }
             gd[v] = g;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s_acc[c * Vp + gv] = 0;
+            acc_clear4<!WARP>(s_acc, Vp, gv);
         }
         if constexpr (WARP) {
             float *gWd = p.grad_warp + pkd * (size_t)VW * 3;
@@ -801,21 +827,26 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                         // scaled by powers of two (exact); pairs, so that weight x pair is one packed multiply
                         const v2f qxy = {dLs.x * s_rgb, dLs.y * s_rgb}, qzw = {dLs.z * s_rgb, dLs.w * s_a};
                         const int gb = (int)fmaf(fz0, (float)(gD - sD), vbf);  // z0 * gD + y0 * gH + x0 (gH = sH)
-                        int *Ap = s_acc + gb;
-#define MVP_FIX1(OFF_, VAL_) atomicAdd(Ap + (OFF_), fix_rn(VAL_));
+                        unsigned long long *Ap = reinterpret_cast<unsigned long long *>(s_acc) + gb;
+// two channels per 64-bit atomic: word = hi * 2^32 + lo (signed lo): low dword lo, high dword hi + (lo >> 31)
+#define MVP_PACK2(LO_, HI_) ((unsigned long long)(uint32_t)(LO_) | ((unsigned long long)(uint32_t)((HI_) + ((LO_) >> 31)) << 32))
+#define MVP_FIX1(OFF_, VLO_, VHI_)                                                    \
+    {                                                                                 \
+        const int lo_ = fix_rn(VLO_), hi_ = fix_rn(VHI_);                             \
+        atomicAdd(Ap + (OFF_), MVP_PACK2(lo_, hi_));                                  \
+    }
 // pass B of a two-pass round: what pass A rounded away, x - rn(x) (exact in fp32), at res_mul units per unit
-#define MVP_FIX1B(OFF_, VAL_)                                                   \
-    {                                                                           \
-        const float x_ = (VAL_);                                                \
-        atomicAdd(Ap + (OFF_), fix_rn((x_ - (float)fix_rn(x_)) * res_mul));     \
+#define MVP_FIX1B(OFF_, VLO_, VHI_)                                                   \
+    {                                                                                 \
+        const float xl_ = (VLO_), xh_ = (VHI_);                                       \
+        const int lo_ = fix_rn((xl_ - (float)fix_rn(xl_)) * res_mul), hi_ = fix_rn((xh_ - (float)fix_rn(xh_)) * res_mul); \
+        atomicAdd(Ap + (OFF_), MVP_PACK2(lo_, hi_));                                  \
     }
 #define MVP_LSCATTER(FIX_, OFF_, MUL_, WP_)                         \
     {                                                               \
         const v2f a_ = MUL_(qxy, WP_), b_ = MUL_(qzw, WP_);         \
-        FIX_((OFF_), a_.x)                                          \
-        FIX_((OFF_) + Vp, a_.y)                                     \
-        FIX_((OFF_) + 2 * Vp, b_.x)                                 \
-        FIX_((OFF_) + 3 * Vp, b_.y)                                 \
+        FIX_((OFF_), a_.x, a_.y)                                    \
+        FIX_((OFF_) + Vp, b_.x, b_.y)                               \
     }
 #define MVP_LSCATTER8(FIX_)                                         \
     MVP_LSCATTER(FIX_, 0, pk_mul_lo, W00)                           \
@@ -835,6 +866,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
 #undef MVP_LSCATTER
 #undef MVP_FIX1B
 #undef MVP_FIX1
+#undef MVP_PACK2
                     }
                     // xmt = (o - pos) + d * t is affine in t along this ray: keep sum(gy) and sum(t * gy) only
                     ra0 += gy.x, ra1 += gy.y, ra2 += gy.z;
@@ -925,10 +957,9 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
-            g.x = (float)s_acc[gv] * i_rgb;
-            g.y = (float)s_acc[Vp + gv] * i_rgb;
-            g.z = (float)s_acc[2 * Vp + gv] * i_rgb;
-            g.w = (float)s_acc[3 * Vp + gv] * i_a;
+            int ia_, ib_, ic_, id_;
+            acc_read4<!WARP>(s_acc, Vp, gv, ia_, ib_, ic_, id_);
+            g.x = (float)ia_ * i_rgb, g.y = (float)ib_ * i_rgb, g.z = (float)ic_ * i_rgb, g.w = (float)id_ * i_a;
             if (drained) {  // (workgroup-uniform) earlier flushes sit in grad_template already; same owner thread
                 const float4 o_ = gT4l[v];
                 g.x = o_.x + g.x, g.y = o_.y + g.y, g.z = o_.z + g.z, g.w = o_.w + g.w;

@@ -112,7 +112,7 @@ def test_half_slab_render_against_oracle_on_the_rounded_slabs(ops, oracle64, cfg
     ok = st["margin"] >= 1e-4
     err = np.abs(out - ref).max(-1)
     assert (err[ok] > FWD_TOL * scale).sum() == 0, (name, float(err[ok].max()), scale)
-    assert (~ok).sum() <= max(2, 0.005 * ok.size)
+    assert (~ok).sum() <= max(2, 0.03 * (st["nsamples"] > 0).sum())   # (the oracle's own margin: up to a few % of the hitting rays of an opaque scene)
     assert np.abs(out[..., 3] - ref[..., 3]).max() <= FWD_TOL
     # storage tolerance against the unrounded fp32 render of the same scene (same schedule, fp32 slabs)
     serr = np.abs(out - full).max(-1)
