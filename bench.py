@@ -394,7 +394,7 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
     if with_bg:  # MFMA utilisation of the dense kernels of this leg: a RECORDED counter pass (tools/make_mfma.py), not this run
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            rec = doc.get("mfma", {}).get(workload)
+            rec = doc.get("mfma", {}).get("C2_bg" if workload == "C2" else workload)
             if rec:
                 out["mfma_frac"] = dict(rec, _what="SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the kernel, against the nominal "
                                                    "peak; recorded pass of tools/evidence.sh", _source=doc.get("_mfma_source"))
@@ -509,6 +509,9 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     ap.add_argument("--opts", default=[], nargs="+", help="key value overrides of the config (ddp-train.py:596)")
     ap.add_argument("--launch-timeout", type=float, default=1800.0,
                     help="self-launched ranks (--gpus N without a launcher) are killed after this many seconds")
+    ap.add_argument("--bg", default="auto", choices=["auto", "on", "off"],
+                    help="--mode train: the background MLP (auto: on except at C2, whose 80-frame batch holds 2 x 54 GB of bf16 "
+                         "activations with it)")
     ap.add_argument("--mode", default="march", choices=["march", "train"],
                     help="march (default, the contract metric + a `train` object); train: only the training loop, as "
                          "the headline value (iterations/s)")
@@ -539,7 +542,8 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             from ava256_amd.config import load_train_config
             cfg = load_train_config(args.config, args.opts)
         t = train_leg(args.workload, args.steps, args.warmup, rank, local_rank, world, dev, dist,
-                      with_bg=args.workload != "C2", ddp=(world > 1 or args.dist_smoke), config=cfg)
+                      with_bg=(args.workload != "C2") if args.bg == "auto" else (args.bg == "on"),
+                      ddp=(world > 1 or args.dist_smoke), config=cfg)
         if rank == 0:
             print(json.dumps({
                 "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",
@@ -618,7 +622,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         if dist is not None:
             dist.all_reduce(free, op=dist.ReduceOp.MIN)
         if float(free.item()) > 160 * (1 << 30):
-            train["C2_bg"] = train_leg("C2", 3, 1, rank, local_rank, world, dev, dist, with_bg=True)
+            train["C2_bg"] = train_leg("C2", 10, 3, rank, local_rank, world, dev, dist, with_bg=True)
 
     if rank == 0:
         rays_per_step = cams_total * H * W

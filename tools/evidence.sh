@@ -4,7 +4,7 @@
 # counters of the train leg (C3: 4 frames, fused bf16 background MLP), the MLP and warp-field microbenchmarks.  Everything lands in gpurun_out/<tag>*/ ; copy what is to
 # be judged into profiles/ and run `python tools/make_traffic.py profiles/<tag>_pmc_fetch.csv profiles/<tag>_pmc_write.csv` in the
 # build container (it stamps traffic.json with the commit), with the SQ and LDS summaries as 4th / 5th argument for `roofline.valu`, and
-# `python tools/make_mfma.py profiles/<tag>_pmc_mfma.csv` for `train.C3.mfma_frac`.
+# `python tools/make_mfma.py profiles/<tag>_pmc_mfma.csv` for `train.C3.mfma_frac` (and `... <tag>_pmc_mfma_c2bg.csv C2_bg` for the 80-frame leg).
 set -u
 TAG=$1
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p $O
@@ -18,6 +18,7 @@ bash tools/pmc.sh ${TAG}_ta "TA_TA_BUSY_sum TA_BUSY_max TCP_TOTAL_CACHE_ACCESSES
 bash tools/pmc.sh ${TAG}_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $M > $O/lds.log 2>&1
 bash tools/pmc.sh ${TAG}_tcc "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" $M > $O/tcc.log 2>&1
 bash tools/pmc_all.sh ${TAG}_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA" --mode train --workload C3 --steps 4 --warmup 2 > $O/mfma.log 2>&1
+bash tools/pmc_all.sh ${TAG}_mfma_c2bg "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA" --mode train --workload C2 --bg on --steps 2 --warmup 1 > $O/mfma_c2bg.log 2>&1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/prof_train; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o train -- python bench.py --mode train --workload C3 --steps 6 --warmup 2 > $O/train_prof.log 2>&1
 find /tmp/prof_train -name "*kernel_stats.csv" -exec cp {} $O/train_C3_kernel_stats.csv \;
