@@ -11,7 +11,7 @@ mkdir -p "$TMP/ava-256_amd" build_variants
 cp -r ava-256_amd/csrc "$TMP/ava-256_amd/csrc"
 cp -r include "$TMP/include"
 if [ "$PATCH" != "-" ]; then
-  (cd "$TMP" && patch -p1 -s < "$OLDPWD/$PATCH")
+  case "$PATCH" in /*) P="$PATCH";; *) P="$PWD/$PATCH";; esac; (cd "$TMP" && patch -p1 -s < "$P")
 fi
 SRCS=$(python3 - <<'PY'
 import importlib.util, os

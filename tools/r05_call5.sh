@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-5 GPU call 5: backward candidates on top of the packed scatter -- padded LDS slab strides and the lean software-
+# pipelined walk: parity tests against each, then A/B timing at C2 / C3 / C4 (two interleaved rounds).
+set -u
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r05e; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_hardening.py -m gpu -x -q > $O/pytest_product.log 2>&1; echo "product: $(tail -1 $O/pytest_product.log)"
+for V in pad975 pipeC; do
+  timeout 900 python tools/pytest_variant.py build_variants/libmvp_$V.so tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_hardening.py -m gpu -x -q > $O/pytest_$V.log 2>&1; echo "$V: $(tail -1 $O/pytest_$V.log)"
+done
+for R in 1 2; do for V in gfx950 pad0 pad975 pipeC pipeCpad0; do
+  L=build_variants/libmvp_$V.so; [ $V = gfx950 ] && L=ava-256_amd/libmvp_gfx950.so
+  for WL in C2 C3 C4; do
+    timeout 300 python tools/bench_variant.py $L --steps 10 --no-render --workload $WL 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('$V $WL round $R: step %.3f fwd %.3f bwd %.3f' % (d['ms_per_step'], d['kernel_ms']['march_forward'], d['kernel_ms']['march_backward']))" | tee -a $O/ab.txt
+  done
+done; done
