@@ -1,10 +1,10 @@
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r05k; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r05l; mkdir -p $O
 for Q in 1 2 4; do python tools/exp_compact_check.py build_variants/libmvp_cmpq$Q.so 2>&1 | tail -1 | tee -a $O/check.txt; done
 for R in 1 2; do
   for WL in C2 C3 C4; do
     for V in gfx950 cmpq1:0 cmpq1:1 cmpq2:0 cmpq2:1 cmpq4:1; do
       N=${V%%:*}; C=${V##*:}; L=build_variants/libmvp_$N.so; [ $N = gfx950 ] && L=ava-256_amd/libmvp_gfx950.so && C=0
-      MVP_COMPACT=$C timeout 300 python tools/bench_variant.py $L --steps 10 --workload $WL --no-workloads 2>/dev/null | python -c "
+      MVP_COMPACT=$C timeout 300 python tools/bench_variant.py $L --steps 10 --workload $WL --no-workloads 2>$O/err_${N}_$C.txt | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
