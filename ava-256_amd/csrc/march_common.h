@@ -520,7 +520,7 @@ __device__ __forceinline__ float4 sample_slab_h(const void *__restrict__ Timg, u
     __builtin_fmaf((float)p10[C_], t.W10.x,                                                                   \
     __builtin_fmaf((float)p01[4 + C_], t.W01.y,                                                               \
     __builtin_fmaf((float)p01[C_], t.W01.x,                                                                   \
-    __builtin_fmaf((float)p00[4 + C_], t.W00.y, (float)p00[C_] * t.W00.x)))))))
+    __builtin_fmaf((float)p00[4 + C_], t.W00.y, __builtin_fmaf((float)p00[C_], t.W00.x, 0.f))))))))
     v.x = MVP_HSUM(0), v.y = MVP_HSUM(1), v.z = MVP_HSUM(2), v.w = MVP_HSUM(3);
 #undef MVP_HSUM
     v.w = v.w * fade;

@@ -300,14 +300,23 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             const bool some = hit && lane_step_range(tn, tf, tmin, tmax, dt, lo, hi);
             if (!some) lo = 0x7fffffff, hi = -1;
             if (__ballot(some) != 0ull) {  // wave-uniform
-                const int wlo = uni(wave_min(lo)), whi = uni(wave_max(hi));
-                if (nh >= kFastSlots || whi > kFastMaxStep) {
-                    wfail = true;
-                    break;
-                }
-                if (lane == nh) {
-                    ent0 = k;
-                    rg0 = wlo | (whi << 16);
+                if constexpr (HALF) {
+                    // render path: no list is handed to a backward, so the packet's step range (two wave reductions per listed
+                    // primitive) is not needed -- only the test that every step index fits the crossing table's field
+                    if (nh >= kFastSlots || __ballot(some && hi > kFastMaxStep) != 0ull) {
+                        wfail = true;
+                        break;
+                    }
+                } else {
+                    const int wlo = uni(wave_min(lo)), whi = uni(wave_max(hi));
+                    if (nh >= kFastSlots || whi > kFastMaxStep) {
+                        wfail = true;
+                        break;
+                    }
+                    if (lane == nh) {
+                        ent0 = k;
+                        rg0 = wlo | (whi << 16);
+                    }
                 }
                 // the record moves to its list slot (nh <= c: nothing unread is overwritten; one wave, in-order LDS)
                 if (inlds) {
@@ -408,7 +417,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
 
     if (MVP_DEBUG_STAGE(p) == 2) nh = 0;
     // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
-    if (!BWD && p.pl_count != nullptr && nh > 0) {
+    if (!BWD && !HALF && p.pl_count != nullptr && nh > 0) {
         uint32_t *flags = p.pl_count + (size_t)p.N * K;
         if (FAST && fast) {
             if (lane < nh) {
@@ -538,7 +547,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                             else
                                 v = sample_slab<FADE8>(T + (size_t)k * V4, y, p.TD, p.TH, p.TW, p.fadescale, p.fadeexp);
                             float contrib;
-                            nanw = nanw || (v.w != v.w);
+                            if constexpr (!HALF) nanw = nanw || (v.w != v.w);   // (only the hand-off to a backward reads it)
                             if (composite(rgba, v, dt, contrib)) {  // saturated: nothing after this sample is evaluated
                                 raysat = mk3(v.x, v.y, v.z);
                                 satkey = ((uint32_t)s << 9) | (uint32_t)slot;
@@ -932,7 +941,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
         }
     }
 
-    if (!BWD && p.pl_count != nullptr) {
+    if (!BWD && !HALF && p.pl_count != nullptr) {
         // max |raysat| over the packet -> tail word [2] (the backward's fixed-point bound).  |-1| = 1 when unsaturated:
         // the host pre-sets the word to 1.0f, and only a packet that can raise it touches it.  (One same-address
         // atomic per packet -- 327 680 of them at C2 -- serialised in L2 and cost 2.5 ms of a 9.4 ms kernel.)
@@ -948,6 +957,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     }
     if (!BWD && inimg) {
         reinterpret_cast<float4 *>(p.rayrgba)[r] = rgba;  // primaccum.h:51-56
+        if constexpr (HALF) return;   // (render path: nothing is handed to a backward)
         if (p.raysat) {
             float *sp = p.raysat + r * 3;
             MVP_STREAM_STOREF(sp, raysat.x), MVP_STREAM_STOREF(sp + 1, raysat.y), MVP_STREAM_STOREF(sp + 2, raysat.z);

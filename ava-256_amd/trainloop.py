@@ -178,11 +178,19 @@ class CodeEncoderStandIn(nn.Module):
 
 
 class SlabDecoderStandIn(nn.Module):
+    # Version of the stand-in's parametrisation.  2 (round 4 on): the per-frame gain multiplies ALL FOUR slab channels -- rgb AND
+    # opacity -- inside the frame-broadcast hand-off kernel (csrc/assemble.hip), so it modulates density and reaches the
+    # primvolsum / alpha gradients; version 1 scaled rgb only and expanded opacity unchanged, with parameters `rgb` / `alpha` /
+    # a K-output gain (now `tex` / `opacity` / a one-output `gain`).  Checkpoints and `train.*` bench numbers of the two
+    # versions are not comparable; the version travels in the state_dict as the buffer `stand_in_version`.
+    STAND_IN_VERSION = 2
+
     def __init__(self, K: int, slab: int = 8, code_dim: int = 16, seed: int = 0, geometry: bool = True,
                  alpha_init: float = 0.5, volradius: float = 256.0, vertstd: float = 10.0):
         super().__init__()
         base = make_primitives(1, K, device="cpu", seed=seed, slab=slab)
         self.K, self.slab, self.geometry, self.volradius = K, slab, geometry, float(volradius)
+        self.register_buffer("stand_in_version", torch.tensor(self.STAND_IN_VERSION, dtype=torch.int32))
         self.register_buffer("base_pos", base["primpos"][0].clone())
         self.register_buffer("base_rot", base["primrot"][0].clone())
         self.register_buffer("base_scale", base["primscale"][0].clone())
