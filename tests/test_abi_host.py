@@ -227,3 +227,21 @@ def test_list_capacity_policy_on_the_host():
     assert capb == 256 and 80 * 4096 * capb * 8 <= 2048 * 80 * 4096
     assert op.primlist_capacity(512, 512, 4096, dev, N=1) == 1880   # one image: 64 MiB allow it
     op._LIST_DEMAND.pop(key, None)
+
+
+def test_half_slab_operators_have_no_cpu_path():
+    """ava-256_amd/halfslab.py: like every operator of this build, the opt-in fp16 render path refuses CPU tensors, wrong dtypes
+    and inputs that require gradients -- before it touches the library."""
+    from ava256_amd import halfslab
+    t = torch.zeros(1, 2, 8, 8, 8, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        halfslab.template_to_half(t)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        halfslab.assemble_template_half(torch.zeros(1, 24, 16, 16), torch.zeros(1, 8, 16, 16), 4)
+    prim = (torch.zeros(1, 2, 3), torch.zeros(1, 2, 3, 3), torch.ones(1, 2, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        halfslab.render_half(torch.zeros(1, 4, 4, 3), torch.zeros(1, 4, 4, 3), 0.1, torch.zeros(1, 4, 4, 2), prim,
+                             t.to(torch.float16))
+    with pytest.raises(RuntimeError, match="no CPU path|renders only"):
+        halfslab.render_half_from_cameras(torch.zeros(1, 3, requires_grad=True), torch.zeros(1, 3, 3), torch.ones(1, 2),
+                                          torch.zeros(1, 2), (4, 4), 1.0, 0.1, prim, t.to(torch.float16))
