@@ -50,6 +50,7 @@ constexpr int kChunk = 16;           // input channels per weight chunk = one MF
 constexpr int kRingElems = kWidth * kChunk;  // bf16 elements per ring buffer (8 KB)
 constexpr int kRing = 3;             // ring buffers: one being multiplied, one being read into fragments, one being written
 constexpr float kSlope = 0.2f;       // LeakyReLU(0.2), mlp2d.py:30-38
+constexpr int kMaskPasses = kTileM * (kWidth / 8) / kThreads;  // 16-byte units of a [tile x 256] bf16 plane per thread: 16
 
 struct Params {
     int B, HW, tiles_per_image;
@@ -307,25 +308,44 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
 
 // dst tile (LDS, bf16) *= leaky'(A) with A from global; result also to global dz
 // `cs` accumulates this thread's 8 columns (c8 = 8 (tid & 31) .. + 7) over its 16 rows: the bias gradient's partial sum
-__device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *__restrict__ A, __bf16 *__restrict__ DZ, int nvalid,
-                                               int tid, float (&cs)[8]) {
-#pragma unroll 2
-    for (int i = tid; i < kTileM * (kWidth / 8); i += kThreads) {
-        const int row = i >> 5, c8 = (i & 31) * 8;
+__device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *A, __bf16 *__restrict__ DZ, int nvalid, int tid,
+                                               float (&cs)[8]) {
+    // All of this thread's activation rows are requested BEFORE the first gradient row is stored: loads and stores
+    // retire through one in-order counter (vmcnt), so a load issued after a store cannot be waited for without waiting
+    // for that store's acknowledgement as well -- interleaved (2 rows per round), every round of this pass paid an HBM
+    // read latency plus a write acknowledgement.  The 64 registers are free here (the accumulators are dead).
+    // The two compiler fences keep the 16 requests where they are written: not above the barrier before this pass (the
+    // accumulators still live there) and not sunk into the loop below, next to their uses (A is deliberately not
+    // __restrict__, and rows past the tile's end are clamped instead of predicated, or the loads are free to move).
+    // (and the 16 clamped offsets are recomputed in every pass -- `tid` made opaque -- or they are kept, and spilled, across
+    //  the whole tile as invariants of the layer loop)
+    asm volatile("; mask pass" : "+v"(tid) : : "memory");
+    bf16x8 av[kMaskPasses];
+#pragma unroll
+    for (int j = 0; j < kMaskPasses; ++j) {
+        // (32-bit element offsets from the tile's uniform base)
+        const unsigned i = tid + j * kThreads, off = min(i >> 5, (unsigned)nvalid - 1u) * kWidth + (i & 31u) * 8u;
+        av[j] = *reinterpret_cast<const bf16x8 *>(A + off);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < kMaskPasses; ++j) {
+        const int i = tid + j * kThreads, row = i >> 5, c8 = (i & 31) * 8;
         bf16x8 g = *reinterpret_cast<const bf16x8 *>(X + row * kLdX + c8);
         if (row < nvalid) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(A + (size_t)row * kWidth + c8);
+            const bf16x8 a = av[j];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 g[e] = (__bf16)((float)g[e] * ((float)a[e] > 0.f ? 1.f : kSlope));
                 cs[e] += (float)g[e];
             }
-            *reinterpret_cast<bf16x8 *>(DZ + (size_t)row * kWidth + c8) = g;
+            *reinterpret_cast<bf16x8 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
         }
         *reinterpret_cast<bf16x8 *>(X + row * kLdX + c8) = g;
+        asm volatile("" ::: "memory");  // one row at a time: 16 LDS rows read ahead next to the 16 requested ones would spill
     }
 }
 
@@ -381,24 +401,35 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e) w6r[c][e] = p.w6[c * kWidth + (tid & 31) * 8 + e];
-        for (int i = tid; i < kTileM * (kWidth / 8); i += kThreads) {
-            const int row = i >> 5, c8 = (tid & 31) * 8;
+        // (fence: W6 is requested before the activations, so waiting for it never means waiting for a later store)
+        asm volatile("" ::: "memory");
+        bf16x8 av[kMaskPasses];  // (requested before the first store, like mask_and_store)
+#pragma unroll
+        for (int j = 0; j < kMaskPasses; ++j) {
+            const unsigned off = min((unsigned)(tid + j * kThreads) >> 5, (unsigned)nvalid - 1u) * kWidth + (tid & 31) * 8;
+            av[j] = *reinterpret_cast<const bf16x8 *>(A + off);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kMaskPasses; ++j) {
+            const int row = (tid + j * kThreads) >> 5, c8 = (tid & 31) * 8;
             const float g0 = gl[row * 3], g1 = gl[row * 3 + 1], g2 = gl[row * 3 + 2];
             bf16x8 g;
             if (row < nvalid) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(A + (size_t)row * kWidth + c8);
+                const bf16x8 a = av[j];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float da = g0 * w6r[0][e] + g1 * w6r[1][e] + g2 * w6r[2][e];
                     g[e] = (__bf16)(da * ((float)a[e] > 0.f ? 1.f : kSlope));
                     cs[e] += (float)g[e];
                 }
-                *reinterpret_cast<bf16x8 *>(DZ + (size_t)row * kWidth + c8) = g;
+                *reinterpret_cast<bf16x8 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
             }
             *reinterpret_cast<bf16x8 *>(X + row * kLdX + c8) = g;
+            asm volatile("" ::: "memory");
         }
     }
     __syncthreads();
