@@ -97,9 +97,19 @@ constexpr int kQueue = 4;  // chunks in flight per thread (registers), i.e. an L
 // q[] is the register queue: on entry q[(G0 + j) % 4] holds chunk G0 + j (j < 4), on exit the same for the next layer
 // (the prefetch runs across layer boundaries).  The caller guarantees the ring is idle on entry (a barrier since its
 // last use, incl. its use as scratch).
-template <int K, int G0, bool FWD>
+// ST: the tile X that this GEMM READS is at the same time what HBM has to receive (forward: the previous layer's
+// activations; backward: the gradient plane just masked; first forward layer: the positional encoding), so its rows leave
+// here, one 16-byte unit per thread and k-step (ST = 1: [rows][256], 16 steps; ST = 2: [rows][48], 3 steps), AFTER that
+// step's weight request.  Loads and stores retire through one in-order counter (vmcnt): a weight chunk requested after a
+// burst of 16 stores per thread could only be waited for once all of them were acknowledged, which serialised every
+// layer's store burst with the GEMM behind it (rounds 3-4: the matrix pipe idle 72 % / 86 % of the two kernels).  In this
+// order the chunk staged in step c (requested in step c - 4) waits for the rows stored up to step c - 5 only.
+template <int K, int G0, bool FWD, int ST>
 __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Params &p, bf16x8 (&q)[kQueue],
-                                          f32x16 (&acc)[2][4], int mq, int nh, int lane, int tid) {
+                                          f32x16 (&acc)[2][4], int mq, int nh, int lane, int tid,
+                                          __bf16 *__restrict__ gdst = nullptr, int nvalid = 0) {
+    static_assert(ST == 0 || (ST == 1 && K / kChunk == kMaskPasses) || (ST == 2 && K == kK0 && kTileM * (kK0 / 8) == 3 * kThreads),
+                  "one store unit per thread and k-step");
     constexpr int NC = K / kChunk, GT = FWD ? kFwdChunks : kBwdChunks;
     const int lr = lane & 31, lk = (lane >> 5) * 8;
     const __bf16 *xa = X + (64 * mq + lr) * kLdX + lk;
@@ -125,6 +135,7 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
     __syncthreads();
     bf16x8 a[2][2], b[2][4];  // [parity of the step][..]
     MVP_FRAGS(a[0], b[0], 0)
+    const bool storing = ST != 0 && gdst != nullptr;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c > 0) __syncthreads();
@@ -141,6 +152,13 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c & 1][ni], a[c & 1][mi], acc[mi][ni], 0, 0, 0);
                 }
             }
+        if (ST != 0) {  // (the row is read from LDS while the step's MFMAs execute)
+            const int si = tid + c * kThreads;
+            const int srow = ST == 2 ? si / (kK0 / 8) : si >> 5, sc8 = ST == 2 ? (si - srow * (kK0 / 8)) * 8 : (si & 31) * 8;
+            if (storing && srow < nvalid)
+                *reinterpret_cast<bf16x8 *>(gdst + (unsigned)(srow * (ST == 2 ? kK0 : kWidth) + sc8)) =
+                    *reinterpret_cast<const bf16x8 *>(X + srow * kLdX + sc8);
+        }
     }
 #undef MVP_STAGE
 #undef MVP_FRAGS
@@ -151,11 +169,15 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
 template <bool ACT>
 __device__ __forceinline__ void acc_to_lds(__bf16 *X, const f32x16 (&acc)[2][4], const float *__restrict__ bias, int mq,
                                            int nh, int lane) {
+    // (opaque per call: otherwise the 16 bias addresses of the five epilogues are one set of loop invariants, kept -- and
+    //  spilled -- across the whole tile)
+    int nb = 128 * nh + 4 * (lane >> 5);
+    asm volatile("; epilogue" : "+v"(nb));
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int n0 = 128 * nh + 32 * ni + 8 * u + 4 * (lane >> 5);
+            const int n0 = nb + 32 * ni + 8 * u;
             float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ACT) {
                 bb = *reinterpret_cast<const float4 *>(bias + n0);
@@ -197,7 +219,18 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     __bf16 *Wr = X + kTileM * kLdX;               // weight ring, 3 x 8 KB
     float *w6s = reinterpret_cast<float *>(Wr);   // [3][256] + [512][3], last layer only (the ring is idle then)
     float *red = w6s + 3 * kWidth;
+    float *bl = reinterpret_cast<float *>(Wr + kRing * kRingElems);  // [256]: the bias of the layer being multiplied
     const int tid0 = threadIdx.x;
+    // The first weight chunks and this thread's pixel of the tile are requested before anything else -- for the first tile
+    // here, for later tiles at the end of the tile before, ahead of its last store burst.
+    bf16x8 q[kQueue];
+    float2 sc = make_float2(0.f, 0.f);
+    if ((int)blockIdx.x < p.B * p.tiles_per_image) {
+#pragma unroll
+        for (int j = 0; j < kQueue; ++j) q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<true>(p, j, tid0));
+        const int b0 = blockIdx.x / p.tiles_per_image, q0 = (blockIdx.x - b0 * p.tiles_per_image) * kTileM + (tid0 & (kTileM - 1));
+        if (q0 < p.HW) sc = reinterpret_cast<const float2 *>(p.samplecoords)[(size_t)b0 * p.HW + q0];
+    }
     // persistent: one workgroup per CU walks its share of the tiles (a launch per tile cost ~4 us of setup each)
     for (int tile = blockIdx.x; tile < p.B * p.tiles_per_image; tile += gridDim.x) {
     // (opaque per iteration: otherwise the ~70 per-thread weight-chunk addresses are hoisted out of the tile loop as
@@ -209,18 +242,11 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     const int b = tile / p.tiles_per_image, p0 = (tile - b * p.tiles_per_image) * kTileM;
     const int nvalid = min(kTileM, p.HW - p0);
     const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
-    bf16x8 q[kQueue];  // the first weight chunks are requested before anything else
-#pragma unroll
-    for (int j = 0; j < kQueue; ++j) q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<true>(p, j, tid));
 
     // ---- positional encoding of the tile (mlp2d.py:64-68): channel 2 i + j = sin(2^i pi x_j), 20 + 2 i + j = cos ----
     {
         const int r = tid & (kTileM - 1), half = tid / kTileM;  // half 0: sines, half 1: cosines + the zero padding
-        float x0 = 0.f, x1 = 0.f;
-        if (r < nvalid) {
-            const float2 sc = reinterpret_cast<const float2 *>(p.samplecoords)[pix0 + r];
-            x0 = sc.x, x1 = sc.y;
-        }
+        const float x0 = r < nvalid ? sc.x : 0.f, x1 = r < nvalid ? sc.y : 0.f;
         __bf16 *row = X + r * kLdX + half * 20;
         // v_sin_f32 / v_cos_f32 take their argument in revolutions: sin(2^i pi x) = v_sin(2^(i-1) x).  Their valid
         // domain is |arg| <= 256 revolutions (outside it the hardware returns sin = 0, cos = 1), which 2^8 x leaves as
@@ -236,41 +262,56 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
             row[2 * i + 1] = (__bf16)(half ? __builtin_amdgcn_cosf(r1) : __builtin_amdgcn_sinf(r1));
             f *= 2.f;
         }
-        if (half) {
-#pragma unroll
-            for (int c = kPos; c < kK0; ++c) X[r * kLdX + c] = (__bf16)0.f;
+        if (half) {  // channels 40..47 = 0 (16 bytes; the zero is made here: as a loop invariant it was kept in scratch)
+            unsigned z = 0;
+            asm volatile("" : "+v"(z));
+            *reinterpret_cast<uint4 *>(X + r * kLdX + kPos) = make_uint4(z, z, z, z);
         }
     }
     __syncthreads();
-    if (p.x0) {  // 96 bytes per pixel, 16 bytes per thread and pass
-        for (int i = tid; i < kTileM * (kK0 / 8); i += kThreads) {
-            const int row = i / (kK0 / 8), c8 = (i - row * (kK0 / 8)) * 8;
-            if (row < nvalid)
-                *reinterpret_cast<bf16x8 *>(p.x0 + (pix0 + row) * kK0 + c8) = *reinterpret_cast<const bf16x8 *>(X + row * kLdX + c8);
-        }
-    }
     f32x16 acc[2][4];
-    // ---- layer 1: 40 (48) -> 256, per-image bias ----
-    tile_gemm<kK0, 0, true>(X, Wr, p, q, acc, mh, nh, lane, tid);
+    // ---- layer 1: 40 (48) -> 256, per-image bias; the positional encoding it reads goes to x0 (96 bytes per pixel) ----
+    // (a layer's bias is requested BEFORE its GEMM and parked in LDS after it: 16 vector loads per thread in the epilogue
+    //  would each wait for the rows the GEMM has just stored)
+    float bv = p.bias1[(size_t)b * kWidth + (tid & (kWidth - 1))];
+    tile_gemm<kK0, 0, true, 2>(X, Wr, p, q, acc, mh, nh, lane, tid, p.x0 ? p.x0 + pix0 * kK0 : nullptr, nvalid);
+    if (tid < kWidth) bl[tid] = bv;
     __syncthreads();
-    acc_to_lds<true>(X, acc, p.bias1 + (size_t)b * kWidth, mh, nh, lane);
+    acc_to_lds<true>(X, acc, bl, mh, nh, lane);
     __syncthreads();
-    if (p.acts) lds_to_global(X, p.acts + pix0 * kWidth, nvalid, tid);
-    // ---- layers 2..5: 256 -> 256 ----
+    // ---- layers 2..5: 256 -> 256; each stores the activations it reads (the previous layer's output) ----
 #define MVP_HIDDEN_LAYER(L_)                                                                              \
-    tile_gemm<kWidth, kK0 / kChunk + (L_) * (kWidth / kChunk), true>(X, Wr, p, q, acc, mh, nh, lane, tid); \
+    {   /* (the plane's address is formed here, not kept in scalar registers from the top of the tile) */ \
+        size_t row0 = (size_t)(L_) * P + pix0;                                                            \
+        asm volatile("" : "+s"(row0));                                                                    \
+        bv = p.bh[(L_) * kWidth + (tid & (kWidth - 1))];                                                  \
+        tile_gemm<kWidth, kK0 / kChunk + (L_) * (kWidth / kChunk), true, 1>(                              \
+            X, Wr, p, q, acc, mh, nh, lane, tid, p.acts ? p.acts + row0 * kWidth : nullptr, nvalid);      \
+        if (tid < kWidth) bl[tid] = bv;                                                                   \
+    }                                                                                                     \
     __syncthreads(); /* every wave has read the whole tile */                                             \
-    acc_to_lds<true>(X, acc, p.bh + (L_) * kWidth, mh, nh, lane);                                         \
-    __syncthreads();                                                                                      \
-    if (p.acts) lds_to_global(X, p.acts + ((size_t)((L_) + 1) * P + pix0) * kWidth, nvalid, tid);
+    if ((L_) == kHidden - 1) { /* the ring is idle: W6 for the last layer, and the next tile's first weight chunks, are  \
+                                  requested before this tile's last store burst, not behind it */           \
+        for (int i = tid; i < 3 * kWidth; i += kThreads) w6s[i] = p.w6[i];                                \
+        const int tn = tile + (int)gridDim.x;                                                             \
+        if (tn < p.B * p.tiles_per_image) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < kQueue; ++j)                                            \
+                q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<true>(p, j, tid));                     \
+            const int bn = tn / p.tiles_per_image, pn = (tn - bn * p.tiles_per_image) * kTileM;           \
+            const int rn = tid & (kTileM - 1);                                                            \
+            if (pn + rn < p.HW) sc = reinterpret_cast<const float2 *>(p.samplecoords)[(size_t)bn * p.HW + pn + rn]; \
+        }                                                                                                 \
+    }                                                                                                     \
+    acc_to_lds<true>(X, acc, bl, mh, nh, lane);                                                           \
+    __syncthreads();
     MVP_HIDDEN_LAYER(0)
     MVP_HIDDEN_LAYER(1)
     MVP_HIDDEN_LAYER(2)
     MVP_HIDDEN_LAYER(3)
 #undef MVP_HIDDEN_LAYER
-    // ---- layer 6: 256 -> 3, * 25 + 100 (mlp2d.py:40,70) ----
-    for (int i = tid; i < 3 * kWidth; i += kThreads) w6s[i] = p.w6[i];  // (per-thread global loads of w6 cost 384 each)
-    __syncthreads();
+    if (p.acts) lds_to_global(X, p.acts + ((size_t)kHidden * P + pix0) * kWidth, nvalid, tid);
+    // ---- layer 6: 256 -> 3, * 25 + 100 (mlp2d.py:40,70); W6 is in the ring already (per-thread global loads of it cost
+    //      384 each) ----
     {
         const int r = tid & (kTileM - 1), half = tid / kTileM;
         const __bf16 *xr = X + r * kLdX + half * 128;
@@ -308,6 +349,8 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
 
 // dst tile (LDS, bf16) *= leaky'(A) with A from global; result also to global dz
 // `cs` accumulates this thread's 8 columns (c8 = 8 (tid & 31) .. + 7) over its 16 rows: the bias gradient's partial sum
+// STORE = false: the masked plane only goes back to LDS; the GEMM that reads it next stores it (tile_gemm, ST = 1)
+template <bool STORE>
 __device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *A, __bf16 *__restrict__ DZ, int nvalid, int tid,
                                                float (&cs)[8]) {
     // All of this thread's activation rows are requested BEFORE the first gradient row is stored: loads and stores
@@ -339,7 +382,7 @@ __device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *A, __bf1
                 g[e] = (__bf16)((float)g[e] * ((float)a[e] > 0.f ? 1.f : kSlope));
                 cs[e] += (float)g[e];
             }
-            *reinterpret_cast<bf16x8 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
+            if (STORE) *reinterpret_cast<bf16x8 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
@@ -370,6 +413,9 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
     float *scratch = reinterpret_cast<float *>(Wr);      // ... doubling as the [16][256] column-sum staging between GEMMs
     float *gl = reinterpret_cast<float *>(Wr + kRing * kRingElems);  // [256][3] upstream gradient * 25
     const int tid0 = threadIdx.x;
+    bf16x8 q[kQueue];  // (later tiles: requested at the end of the tile before, ahead of its last stores)
+#pragma unroll
+    for (int j = 0; j < kQueue; ++j) q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<false>(p, j, tid0));
     for (int tile = blockIdx.x; tile < p.B * p.tiles_per_image; tile += gridDim.x) {
     int tid = tid0;
     asm volatile("; per-tile thread index" : "+v"(tid));
@@ -378,9 +424,6 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
     const int b = tile / p.tiles_per_image, p0 = (tile - b * p.tiles_per_image) * kTileM;
     const int nvalid = min(kTileM, p.HW - p0);
     const size_t P = (size_t)p.B * p.HW, pix0 = (size_t)b * p.HW + p0;
-    bf16x8 q[kQueue];
-#pragma unroll
-    for (int j = 0; j < kQueue; ++j) q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<false>(p, j, tid));
 
     if (tid < kTileM) {
 #pragma unroll
@@ -394,8 +437,7 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
     {
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-        const __bf16 *A = p.acts + (4 * P + pix0) * kWidth;
-        __bf16 *DZ = p.dz + (4 * P + pix0) * kWidth;
+        const __bf16 *A = p.acts + (4 * P + pix0) * kWidth;  // (dZ5 itself is stored by the GEMM that reads it)
         float w6r[3][8];  // this thread's 8 columns of W6 (c8 below is the same in every pass)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -423,7 +465,6 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
                     g[e] = (__bf16)(da * ((float)a[e] > 0.f ? 1.f : kSlope));
                     cs[e] += (float)g[e];
                 }
-                *reinterpret_cast<bf16x8 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
@@ -439,13 +480,19 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
 #define MVP_BWD_LAYER(I_)                                                                                            \
     {                                                                                                                \
         constexpr int l = kHidden - 1 - (I_);                                                                        \
-        tile_gemm<kWidth, (I_) * (kWidth / kChunk), false>(X, Wr, p, q, acc, mh, nh, lane, tid); /* transposed W */   \
+        /* transposed W; the plane dZ_(l+1) it reads goes to HBM from here */                                        \
+        tile_gemm<kWidth, (I_) * (kWidth / kChunk), false, 1>(X, Wr, p, q, acc, mh, nh, lane, tid,                   \
+                                                              p.dz + ((size_t)(l + 1) * P + pix0) * kWidth, nvalid); \
         __syncthreads();                                                                                             \
         acc_to_lds<false>(X, acc, nullptr, mh, nh, lane);                                                            \
         __syncthreads();                                                                                             \
         for (int e = 0; e < 8; ++e) cs[e] = 0.f;                                                                     \
-        mask_and_store(X, p.acts + ((size_t)l * P + pix0) * kWidth, p.dz + ((size_t)l * P + pix0) * kWidth, nvalid,  \
-                       tid, cs);                                                                                     \
+        if (l == 0 && tile + (int)gridDim.x < p.B * p.tiles_per_image) { /* next tile's weights: ahead of the stores */ \
+            _Pragma("unroll") for (int j = 0; j < kQueue; ++j)                                                       \
+                q[j] = *reinterpret_cast<const bf16x8 *>(chunk_ptr<false>(p, j, tid));                               \
+        }                                                                                                            \
+        mask_and_store<l == 0>(X, p.acts + ((size_t)l * P + pix0) * kWidth, p.dz + ((size_t)l * P + pix0) * kWidth,  \
+                               nvalid, tid, cs);                                                                     \
         __syncthreads();                                                                                             \
         reduce_colsum(scratch, cs, p.colsum + ((size_t)l * ntiles + tile) * kWidth, tid);                           \
     }
@@ -496,8 +543,8 @@ extern "C" int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const
     p.samplecoords = samplecoords, p.bias1 = bias1, p.w1pos = static_cast<const __bf16 *>(w1pos);
     p.wh = static_cast<const __bf16 *>(wh), p.bh = bh, p.w6 = w6, p.b6 = b6;
     p.acts = static_cast<__bf16 *>(acts), p.x0 = static_cast<__bf16 *>(x0), p.out = out;
-    const size_t lds = (size_t)kTileM * kLdX * 2 + kRing * kRingElems * 2;
-    // 156 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU)
+    const size_t lds = (size_t)kTileM * kLdX * 2 + kRing * kRingElems * 2 + kWidth * sizeof(float);
+    // 157 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)persistent_grid(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
