@@ -18,7 +18,18 @@
 // L2 round trip is covered by three chunks of MFMA work, and a weight element is read once per 256 pixels.  (A first
 // version with 128-pixel tiles whose waves read their B fragments straight from global memory ran at 370 TFLOP/s:
 // each k-step waited for an L2 round trip.)  Bias + LeakyReLU are applied on the accumulators, the result goes back to
-// LDS as the next layer's input and (training) to HBM once, as bf16, for the backward.  The camera / identity codes enter as a
+// LDS as the next layer's input and (training) to HBM once, as bf16, for the backward.
+// HOW THE PLANES REACH HBM (round 5).  Vector loads and stores retire through ONE in-order counter (vmcnt), so a load
+// issued after a store can only be waited for together with that store's acknowledgement.  Rounds 3-4 stored a layer's
+// plane as a burst of 16 rows per thread right after the epilogue: the next GEMM's first weight request then waited for
+// the whole burst to drain (forward), and the backward's mask pass, which alternated 2 activation loads with 2 gradient
+// stores, paid a read latency plus a write acknowledgement per round -- the matrix pipe was busy 28 % / 14 % of the two
+// kernels and the waves parked 42 % / 65 % of their time.  Now (a) a plane leaves from inside the GEMM that READS it (the
+// tile is constant then), one row per thread and k-step, issued after that step's weight request (tile_gemm, ST); (b) a
+// mask pass requests all 16 activation rows before it stores anything; (c) biases are requested before the GEMM and parked
+// in LDS, W6 and the next tile's first weight chunks and pixel are requested ahead of the tile's last burst.  Same
+// arithmetic, same bytes: backward 1.54 -> 0.95 ms, forward (training) 0.93 -> ~0.75 ms at 4 x 512^2
+// (profiles/r05_bgmlp_counters.txt), MFMA busy 0.36 / 0.23.  The camera / identity codes enter as a
 // per-image bias of the first layer (their 80 input channels are constant over the image), so the first GEMM has
 // K = 40 (padded to 48).  The last layer (256 -> 3) is a VALU dot product.
 //
@@ -38,6 +49,7 @@ namespace bgmlp {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int kTileM = 256;          // pixels per workgroup tile
 constexpr int kWidth = 256;          // hidden width
@@ -189,13 +201,14 @@ __device__ __forceinline__ void acc_to_lds(__bf16 *X, const f32x16 (&acc)[2][4],
                 const int pix = 64 * mq + 32 * mi + (lane & 31);
                 bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[mi][ni][4 * u + e];
+                for (int h = 0; h < 2; ++h) {  // two channels per packed operation
+                    f32x2 v = {acc[mi][ni][4 * u + 2 * h], acc[mi][ni][4 * u + 2 * h + 1]};
                     if (ACT) {
-                        v += bv[e];
-                        v = fmaxf(v, kSlope * v);  // LeakyReLU(0.2): max(v, 0.2 v)
+                        v += f32x2{bv[2 * h], bv[2 * h + 1]};
+                        const f32x2 sl = v * f32x2{kSlope, kSlope};
+                        v.x = fmaxf(v.x, sl.x), v.y = fmaxf(v.y, sl.y);  // LeakyReLU(0.2): max(v, 0.2 v)
                     }
-                    o[e] = (__bf16)v;
+                    o[2 * h] = (__bf16)v.x, o[2 * h + 1] = (__bf16)v.y;
                 }
                 *reinterpret_cast<bf16x4 *>(X + pix * kLdX + n0) = o;
             }
@@ -347,6 +360,34 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     }
 }
 
+// Eight gradients (4 words of two bf16) times leaky'(activation), as bf16 again; `cs` += the eight products.  Per pair:
+// two shifts / masks to fp32, the two slopes from the activations' bits (lower half: its fp32 value > 0; upper half: the
+// word as a signed integer > 0xffff, i.e. sign clear and a non-zero bf16 -- a positive NaN counts as positive), one packed
+// multiply, one packed add, one packed conversion: 5 operations per element less than element by element.
+__device__ __forceinline__ uint4 mask8f(const f32x2 (&gv)[4], const uint4 a, f32x2 (&cs)[4]) {  // gradients given in fp32
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w};
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x2 m;
+        m.x = __uint_as_float(aw[k] << 16) > 0.f ? 1.f : kSlope;
+        m.y = (int)aw[k] > 0xffff ? 1.f : kSlope;
+        const f32x2 pr = gv[k] * m;
+        cs[k] += pr;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        const bf16x2 r = {(__bf16)pr.x, (__bf16)pr.y};
+        o[k] = __builtin_bit_cast(unsigned, r);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ uint4 mask8(const uint4 g, const uint4 a, f32x2 (&cs)[4]) {
+    const unsigned gw[4] = {g.x, g.y, g.z, g.w};
+    f32x2 gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gv[k].x = __uint_as_float(gw[k] << 16), gv[k].y = __uint_as_float(gw[k] & 0xffff0000u);
+    return mask8f(gv, a, cs);
+}
+
 // dst tile (LDS, bf16) *= leaky'(A) with A from global; result also to global dz
 // `cs` accumulates this thread's 8 columns (c8 = 8 (tid & 31) .. + 7) over its 16 rows: the bias gradient's partial sum
 // STORE = false: the masked plane only goes back to LDS; the GEMM that reads it next stores it (tile_gemm, ST = 1)
@@ -363,33 +404,32 @@ __device__ __forceinline__ void mask_and_store(__bf16 *X, const __bf16 *A, __bf1
     // (and the 16 clamped offsets are recomputed in every pass -- `tid` made opaque -- or they are kept, and spilled, across
     //  the whole tile as invariants of the layer loop)
     asm volatile("; mask pass" : "+v"(tid) : : "memory");
-    bf16x8 av[kMaskPasses];
+    f32x2 cs2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs2[k] = f32x2{cs[2 * k], cs[2 * k + 1]};
+    uint4 av[kMaskPasses];
 #pragma unroll
     for (int j = 0; j < kMaskPasses; ++j) {
         // (32-bit element offsets from the tile's uniform base)
         const unsigned i = tid + j * kThreads, off = min(i >> 5, (unsigned)nvalid - 1u) * kWidth + (i & 31u) * 8u;
-        av[j] = *reinterpret_cast<const bf16x8 *>(A + off);
+        av[j] = *reinterpret_cast<const uint4 *>(A + off);
     }
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < kMaskPasses; ++j) {
         const int i = tid + j * kThreads, row = i >> 5, c8 = (i & 31) * 8;
-        bf16x8 g = *reinterpret_cast<const bf16x8 *>(X + row * kLdX + c8);
+        uint4 g = *reinterpret_cast<const uint4 *>(X + row * kLdX + c8);
         if (row < nvalid) {
-            const bf16x8 a = av[j];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                g[e] = (__bf16)((float)g[e] * ((float)a[e] > 0.f ? 1.f : kSlope));
-                cs[e] += (float)g[e];
-            }
-            if (STORE) *reinterpret_cast<bf16x8 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
+            g = mask8(g, av[j], cs2);
+            if (STORE) *reinterpret_cast<uint4 *>(DZ + (unsigned)(row * kWidth + c8)) = g;
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
+            g = make_uint4(0u, 0u, 0u, 0u);
         }
-        *reinterpret_cast<bf16x8 *>(X + row * kLdX + c8) = g;
+        *reinterpret_cast<uint4 *>(X + row * kLdX + c8) = g;
         asm volatile("" ::: "memory");  // one row at a time: 16 LDS rows read ahead next to the 16 requested ones would spill
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs[2 * k] = cs2[k].x, cs[2 * k + 1] = cs2[k].y;
 }
 
 // column sums of the tile: 16 threads (tid >> 5) hold partial sums of the same 8 columns -> LDS -> one row of `out`
@@ -435,43 +475,41 @@ __global__ __launch_bounds__(kThreads, 1) void bwd_kernel(const Params p) {
     float cs[8];
     // ---- dA5 = g . W6 (K = 3: VALU), dZ5 = dA5 * leaky'(A5) ----
     {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
         const __bf16 *A = p.acts + (4 * P + pix0) * kWidth;  // (dZ5 itself is stored by the GEMM that reads it)
-        float w6r[3][8];  // this thread's 8 columns of W6 (c8 below is the same in every pass)
+        f32x2 w6r[3][4];  // this thread's 8 columns of W6 (c8 below is the same in every pass), as pairs
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w6r[c][e] = p.w6[c * kWidth + (tid & 31) * 8 + e];
+            for (int k = 0; k < 4; ++k)
+                w6r[c][k] = f32x2{p.w6[c * kWidth + (tid & 31) * 8 + 2 * k], p.w6[c * kWidth + (tid & 31) * 8 + 2 * k + 1]};
+        f32x2 cs2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs2[k] = f32x2{0.f, 0.f};
         // (fence: W6 is requested before the activations, so waiting for it never means waiting for a later store)
         asm volatile("" ::: "memory");
-        bf16x8 av[kMaskPasses];  // (requested before the first store, like mask_and_store)
+        uint4 av[kMaskPasses];  // (requested before the first store, like mask_and_store)
 #pragma unroll
         for (int j = 0; j < kMaskPasses; ++j) {
             const unsigned off = min((unsigned)(tid + j * kThreads) >> 5, (unsigned)nvalid - 1u) * kWidth + (tid & 31) * 8;
-            av[j] = *reinterpret_cast<const bf16x8 *>(A + off);
+            av[j] = *reinterpret_cast<const uint4 *>(A + off);
         }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < kMaskPasses; ++j) {
             const int row = (tid + j * kThreads) >> 5, c8 = (tid & 31) * 8;
             const float g0 = gl[row * 3], g1 = gl[row * 3 + 1], g2 = gl[row * 3 + 2];
-            bf16x8 g;
+            uint4 g = make_uint4(0u, 0u, 0u, 0u);
             if (row < nvalid) {
-                const bf16x8 a = av[j];
+                f32x2 da[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float da = g0 * w6r[0][e] + g1 * w6r[1][e] + g2 * w6r[2][e];
-                    g[e] = (__bf16)(da * ((float)a[e] > 0.f ? 1.f : kSlope));
-                    cs[e] += (float)g[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = (__bf16)0.f;
+                for (int k = 0; k < 4; ++k) da[k] = f32x2{g0, g0} * w6r[0][k] + f32x2{g1, g1} * w6r[1][k] + f32x2{g2, g2} * w6r[2][k];
+                g = mask8f(da, av[j], cs2);
             }
-            *reinterpret_cast<bf16x8 *>(X + row * kLdX + c8) = g;
+            *reinterpret_cast<uint4 *>(X + row * kLdX + c8) = g;
             asm volatile("" ::: "memory");
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs[2 * k] = cs2[k].x, cs[2 * k + 1] = cs2[k].y;
     }
     __syncthreads();
     reduce_colsum(scratch, cs, p.colsum + (4 * ntiles + tile) * kWidth, tid);

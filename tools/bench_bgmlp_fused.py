@@ -1,9 +1,14 @@
 """Time the background MLP (forward, forward + backward) at B x H x W: fused MFMA kernels vs eager bf16 autocast.
-usage: python tools/bench_bgmlp_fused.py [B H W]"""
+usage: python tools/bench_bgmlp_fused.py [B H W [variant library]]   (with a build_variants/ library: fused only -- timing
+experiments compute wrong results by construction)"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import __graft_entry__  # noqa: F401
+from ava256_amd import _lib
+VARIANT = sys.argv[4] if len(sys.argv) >= 5 else None
+if VARIANT:
+    _lib.use_library(os.path.abspath(VARIANT))
 from ava256_amd.trainloop import BackgroundMLPStandIn
 
 B, H, W = [int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (4, 512, 512))]
@@ -29,7 +34,9 @@ def timeit(fn, n=5):
 
 
 out = dict(B=B, H=H, W=W, gflop_fwd=round(flop_fwd * 1e-9, 1))
-for name, fused in (("fused", True), ("eager", False)):
+if VARIANT:
+    out["library"] = VARIANT
+for name, fused in ((("fused", True),) if VARIANT else (("fused", True), ("eager", False))):
     m = BackgroundMLPStandIn(5, 3, fused=fused).cuda()
 
     def fwd():
