@@ -40,7 +40,7 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, chunks: int = 64) -> torch.Tensor:
 
 class _FusedBgMlp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, samplecoords, bias1, w1pos, w6, b6, *hidden):
+    def forward(ctx, train, samplecoords, bias1, w1pos, w6, b6, *hidden):
         # hidden = (W2, b2, W3, b3, W4, b4, W5, b5): weights [256,256] ([out][in]), biases [256]
         if not samplecoords.is_cuda:
             raise RuntimeError("fused background MLP: CUDA/HIP tensors only (no CPU fallback)")
@@ -59,7 +59,9 @@ class _FusedBgMlp(torch.autograd.Function):
         whb = torch.stack([hidden[2 * i].detach() for i in range(HIDDEN)]).to(torch.bfloat16).contiguous()
         bhf = torch.stack([hidden[2 * i + 1].detach() for i in range(HIDDEN)]).float().contiguous()
         b1f, w6f, b6f = bias1.detach().float().contiguous(), w6.detach().float().contiguous(), b6.detach().float().contiguous()
-        need_grad = any(ctx.needs_input_grad)
+        # `train` (fused_background_mlp): grad mode is on and something requires a gradient.  ctx.needs_input_grad alone
+        # also says True under torch.no_grad() -- the inference kernel (no stores at all) would never run
+        need_grad = bool(train) and any(ctx.needs_input_grad)
         acts = torch.empty((HIDDEN + 1, B * HW, WIDTH), device=dev, dtype=torch.bfloat16) if need_grad else None
         x0 = torch.empty((B * HW, POS_PAD), device=dev, dtype=torch.bfloat16) if need_grad else None
         out = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
@@ -98,11 +100,12 @@ class _FusedBgMlp(torch.autograd.Function):
         hidden = []
         for l in range(HIDDEN):
             hidden += [g_wh[l], g_bh[l]]
-        return (None, g_bias1, g_w1pos, g_w6, g_b6, *hidden)
+        return (None, None, g_bias1, g_w1pos, g_w6, g_b6, *hidden)
 
 
 def fused_background_mlp(samplecoords, bias1, w1pos, hidden, w6, b6):
     """samplecoords [B,H,W,2]; bias1 [B,256] (first-layer bias incl. the camera / identity codes); w1pos [256,40];
     hidden = [(W, b)] x 4; w6 [3,256]; b6 [3]  ->  [B,3,H,W] = MLP * 25 + 100 (mlp2d.py:69-70)."""
     flat = [t for wb in hidden for t in wb]
-    return _FusedBgMlp.apply(samplecoords, bias1, w1pos, w6, b6, *flat)
+    train = torch.is_grad_enabled() and any(t.requires_grad for t in (bias1, w1pos, w6, b6, *flat))
+    return _FusedBgMlp.apply(train, samplecoords, bias1, w1pos, w6, b6, *flat)

@@ -164,7 +164,9 @@ __device__ __forceinline__ void tile_gemm(const __bf16 *X, __bf16 *Wr, const Par
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c & 1][ni], a[c & 1][mi], acc[mi][ni], 0, 0, 0);
                 }
             }
-        if (ST != 0) {  // (the row is read from LDS while the step's MFMAs execute)
+        if (ST != 0) {  // (the row is read from LDS while the step's MFMAs execute.  Predicated on the row being inside
+                        //  the tile; a straight-line version -- rows past the end clamped to the last valid one -- measured
+                        //  3 % slower: it stretches the step's live ranges)
             const int si = tid + c * kThreads;
             const int srow = ST == 2 ? si / (kK0 / 8) : si >> 5, sc8 = ST == 2 ? (si - srow * (kK0 / 8)) * 8 : (si & 31) * 8;
             if (storing && srow < nvalid)
@@ -226,6 +228,8 @@ __device__ __forceinline__ void lds_to_global(const __bf16 *X, __bf16 *__restric
     }
 }
 
+// TRAIN: the planes the backward needs (x0, acts) are written; false = inference, no store code at all
+template <bool TRAIN>
 __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16 *X = reinterpret_cast<__bf16 *>(smem);
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     // (a layer's bias is requested BEFORE its GEMM and parked in LDS after it: 16 vector loads per thread in the epilogue
     //  would each wait for the rows the GEMM has just stored)
     float bv = p.bias1[(size_t)b * kWidth + (tid & (kWidth - 1))];
-    tile_gemm<kK0, 0, true, 2>(X, Wr, p, q, acc, mh, nh, lane, tid, p.x0 ? p.x0 + pix0 * kK0 : nullptr, nvalid);
+    tile_gemm<kK0, 0, true, TRAIN ? 2 : 0>(X, Wr, p, q, acc, mh, nh, lane, tid, p.x0 ? p.x0 + pix0 * kK0 : nullptr, nvalid);
     if (tid < kWidth) bl[tid] = bv;
     __syncthreads();
     acc_to_lds<true>(X, acc, bl, mh, nh, lane);
@@ -296,9 +300,9 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
 #define MVP_HIDDEN_LAYER(L_)                                                                              \
     {   /* (the plane's address is formed here, not kept in scalar registers from the top of the tile) */ \
         size_t row0 = (size_t)(L_) * P + pix0;                                                            \
-        asm volatile("" : "+s"(row0));                                                                    \
+        if (TRAIN) asm volatile("" : "+s"(row0));                                                         \
         bv = p.bh[(L_) * kWidth + (tid & (kWidth - 1))];                                                  \
-        tile_gemm<kWidth, kK0 / kChunk + (L_) * (kWidth / kChunk), true, 1>(                              \
+        tile_gemm<kWidth, kK0 / kChunk + (L_) * (kWidth / kChunk), true, TRAIN ? 1 : 0>(                  \
             X, Wr, p, q, acc, mh, nh, lane, tid, p.acts ? p.acts + row0 * kWidth : nullptr, nvalid);      \
         if (tid < kWidth) bl[tid] = bv;                                                                   \
     }                                                                                                     \
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(kThreads, 1) void fwd_kernel(const Params p) {
     MVP_HIDDEN_LAYER(2)
     MVP_HIDDEN_LAYER(3)
 #undef MVP_HIDDEN_LAYER
-    if (p.acts) lds_to_global(X, p.acts + ((size_t)kHidden * P + pix0) * kWidth, nvalid, tid);
+    if (TRAIN && p.acts) lds_to_global(X, p.acts + ((size_t)kHidden * P + pix0) * kWidth, nvalid, tid);
     // ---- layer 6: 256 -> 3, * 25 + 100 (mlp2d.py:40,70); W6 is in the ring already (per-thread global loads of it cost
     //      384 each) ----
     {
@@ -578,14 +582,20 @@ extern "C" int mvp_bgmlp_forward(int B, int HW, const float *samplecoords, const
     if (!aligned16(w1pos) || !aligned16(wh) || (acts && !aligned16(acts)) || (x0 && !aligned16(x0)) ||
         !aligned16(bias1) || !aligned16(bh) || ((uintptr_t)samplecoords & 7u))
         return MVP_ERR_BADARG;
+    if ((acts != nullptr) != (x0 != nullptr)) return MVP_ERR_BADARG;  // the two training planes go together
     p.samplecoords = samplecoords, p.bias1 = bias1, p.w1pos = static_cast<const __bf16 *>(w1pos);
     p.wh = static_cast<const __bf16 *>(wh), p.bh = bh, p.w6 = w6, p.b6 = b6;
     p.acts = static_cast<__bf16 *>(acts), p.x0 = static_cast<__bf16 *>(x0), p.out = out;
     const size_t lds = (size_t)kTileM * kLdX * 2 + kRing * kRingElems * 2 + kWidth * sizeof(float);
     // 157 KB of dynamic LDS: above the 64 KB default limit (gfx950 has 160 KB per CU)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void *fn = acts ? reinterpret_cast<const void *>(fwd_kernel<true>) : reinterpret_cast<const void *>(fwd_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)persistent_grid(B * p.tiles_per_image)), dim3(kThreads), lds, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)persistent_grid(B * p.tiles_per_image));
+    if (acts)
+        hipLaunchKernelGGL(fwd_kernel<true>, grid, dim3(kThreads), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(fwd_kernel<false>, grid, dim3(kThreads), lds, (hipStream_t)stream, p);
     return launch_status();
 }
 

@@ -288,6 +288,7 @@ int mvp_grads_clip_scale(int ntensors, float *const *grads, const long long *num
  *   bh     [4,256] float32, w6 [3,256] float32, b6 [3] float32
  *   acts   [5, B*HW, 256] bf16, written when not NULL: the post-activation outputs of the five hidden layers
  *   x0     [B*HW, 48] bf16, written when not NULL: the positional encoding as the first GEMM consumed it
+ *          (acts and x0: both or neither -- with neither, the inference instantiation runs, which has no store code)
  *   out    [B,3,HW] float32 (NCHW planes)
  * bf16 operands, fp32 accumulation.  Backward: dz [5, B*HW, 256] bf16 = gradients w.r.t. the five pre-activations
  * (the chain of input gradients), from grad_out [B,3,HW] and `acts`; whT holds the transposed hidden weights
