@@ -397,7 +397,7 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
             rec = doc.get("mfma", {}).get("C2_bg" if workload == "C2" else workload)
             if rec:
                 out["mfma_frac"] = dict(rec, _what="SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the kernel, against the nominal "
-                                                   "peak; recorded pass of tools/evidence.sh", _source=doc.get("_mfma_source"))
+                                                   "peak; recorded pass of tools/evidence.sh", _source=rec.get("_source", doc.get("_mfma_source")))
         except Exception:
             pass
     del tr, model, batch

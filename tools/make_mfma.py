@@ -28,8 +28,9 @@ def main():
                 out[name] = round(frac, 4)
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     doc = json.load(open(tf)) if os.path.exists(tf) else {}
+    out["_source"] = os.path.relpath(os.path.abspath(path), ROOT)  # (per workload: the two legs come from two passes)
     doc.setdefault("mfma", {})[workload] = out
-    doc["_mfma_source"] = os.path.relpath(os.path.abspath(path), ROOT)
+    doc["_mfma_source"] = out["_source"]
     json.dump(doc, open(tf, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
