@@ -103,9 +103,24 @@ class _FusedBgMlp(torch.autograd.Function):
         return (None, None, g_bias1, g_w1pos, g_w6, g_b6, *hidden)
 
 
-def fused_background_mlp(samplecoords, bias1, w1pos, hidden, w6, b6):
+IMAGES_PER_CALL = 16  # training: images per kernel pair (see fused_background_mlp)
+
+
+def fused_background_mlp(samplecoords, bias1, w1pos, hidden, w6, b6, images_per_call=None):
     """samplecoords [B,H,W,2]; bias1 [B,256] (first-layer bias incl. the camera / identity codes); w1pos [256,40];
-    hidden = [(W, b)] x 4; w6 [3,256]; b6 [3]  ->  [B,3,H,W] = MLP * 25 + 100 (mlp2d.py:69-70)."""
+    hidden = [(W, b)] x 4; w6 [3,256]; b6 [3]  ->  [B,3,H,W] = MLP * 25 + 100 (mlp2d.py:69-70).
+
+    Training keeps 2.6 KB per pixel for the backward (five bf16 activation planes + the positional encoding) and the
+    backward makes as much again (the five gradient planes the weight-gradient GEMMs read): at 80 x 512^2 pixels 2 x 54 GB
+    if everything is one call.  A batch is therefore walked in groups of `images_per_call` images (default
+    IMAGES_PER_CALL), each its own autograd node: the activation planes of all groups stay until their backward, the
+    gradient planes exist for one group at a time (80 frames: 54 + 11 GB).  Tiles never span images, so the output bits do
+    not depend on the grouping; weight gradients are summed over the groups in fp32 by autograd."""
     flat = [t for wb in hidden for t in wb]
     train = torch.is_grad_enabled() and any(t.requires_grad for t in (bias1, w1pos, w6, b6, *flat))
-    return _FusedBgMlp.apply(train, samplecoords, bias1, w1pos, w6, b6, *flat)
+    B = samplecoords.shape[0]
+    n = int(images_per_call or IMAGES_PER_CALL)
+    if not train or B <= n:
+        return _FusedBgMlp.apply(train, samplecoords, bias1, w1pos, w6, b6, *flat)
+    return torch.cat([_FusedBgMlp.apply(train, samplecoords[i:i + n], bias1[i:i + n], w1pos, w6, b6, *flat)
+                      for i in range(0, B, n)], dim=0)

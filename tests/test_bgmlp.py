@@ -159,3 +159,34 @@ def test_inference_path_equals_training_path():
     b = m(cam, idx, sc)
     assert b.requires_grad and not a.requires_grad
     assert torch.equal(a, b.detach())
+
+
+@pytest.mark.gpu
+def test_image_groups_do_not_change_the_result():
+    """fused_background_mlp walks a training batch in groups of images (bgmlp.IMAGES_PER_CALL) so that the gradient planes
+    exist for one group at a time: same output bits (tiles never span images), weight gradients equal up to the fp32
+    summation order over the groups."""
+    from ava256_amd import bgmlp
+    gen = torch.Generator().manual_seed(5)
+    B, H, W = 3, 24, 40
+    sc = (torch.rand(B, H, W, 2, generator=gen) * 2 - 1).cuda()
+    mk = lambda *shape, s=0.1: (torch.randn(*shape, generator=gen) * s).cuda().requires_grad_(True)
+    bias1, w1pos, w6, b6 = mk(B, 256), mk(256, 40), mk(3, 256), mk(3)
+    hidden = [(mk(256, 256, s=0.06), mk(256)) for _ in range(4)]
+    gout = torch.randn(B, 3, H, W, generator=gen).cuda()
+    params = [bias1, w1pos, w6, b6] + [t for wb in hidden for t in wb]
+
+    def run(n):
+        for t in params:
+            t.grad = None
+        out = bgmlp.fused_background_mlp(sc, bias1, w1pos, hidden, w6, b6, images_per_call=n)
+        out.backward(gout)
+        return out.detach().clone(), [t.grad.detach().clone() for t in params]
+
+    o1, g1 = run(B)   # one call
+    o2, g2 = run(1)   # one call per image
+    o3, g3 = run(2)   # ragged grouping: 2 + 1
+    assert torch.equal(o1, o2) and torch.equal(o1, o3)
+    for a, b, c in zip(g1, g2, g3):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-3 * scale and float((a - c).abs().max()) <= 2e-3 * scale
