@@ -13,12 +13,15 @@
 // activations of the tile stay in LDS as bf16 ([256][256 + 8], 132 KB: the 16-byte pad makes the MFMA A-fragment reads
 // conflict-free); each wave computes a 64 x 128 block of the tile's [256 x 256] output with v_mfma_f32_32x32x16_bf16
 // (8 accumulator tiles = 128 registers).  The weights (128 KB per layer, L2-resident, nn.Linear layout [out][in]: the 8
-// consecutive input channels a B fragment needs are 16 contiguous bytes) stream through a 2 x 8 KB LDS ring in chunks of
+// consecutive input channels a B fragment needs are 16 contiguous bytes) stream through a 3 x 8 KB LDS ring in chunks of
 // 16 input channels: every thread fetches 16 bytes of chunk c + 4 into a register while chunk c is multiplied, so an
-// L2 round trip is covered by three chunks of MFMA work, and a weight element is read once per 256 pixels.  (A first
+// L2 round trip is covered by four chunks of MFMA work, and a weight element is read once per 256 pixels.  (A first
 // version with 128-pixel tiles whose waves read their B fragments straight from global memory ran at 370 TFLOP/s:
 // each k-step waited for an L2 round trip.)  Bias + LeakyReLU are applied on the accumulators, the result goes back to
-// LDS as the next layer's input and (training) to HBM once, as bf16, for the backward.
+// LDS as the next layer's input and (training) to HBM once, as bf16, for the backward.  The camera / identity codes enter
+// as a per-image bias of the first layer (their 80 input channels are constant over the image), so the first GEMM has
+// K = 40 (padded to 48).  The last layer (256 -> 3) is a VALU dot product.
+//
 // HOW THE PLANES REACH HBM (round 5).  Vector loads and stores retire through ONE in-order counter (vmcnt), so a load
 // issued after a store can only be waited for together with that store's acknowledgement.  Rounds 3-4 stored a layer's
 // plane as a burst of 16 rows per thread right after the epilogue: the next GEMM's first weight request then waited for
@@ -28,10 +31,9 @@
 // tile is constant then), one row per thread and k-step, issued after that step's weight request (tile_gemm, ST); (b) a
 // mask pass requests all 16 activation rows before it stores anything; (c) biases are requested before the GEMM and parked
 // in LDS, W6 and the next tile's first weight chunks and pixel are requested ahead of the tile's last burst.  Same
-// arithmetic, same bytes: backward 1.54 -> 0.95 ms, forward (training) 0.93 -> ~0.75 ms at 4 x 512^2
-// (profiles/r05_bgmlp_counters.txt), MFMA busy 0.36 / 0.23.  The camera / identity codes enter as a
-// per-image bias of the first layer (their 80 input channels are constant over the image), so the first GEMM has
-// K = 40 (padded to 48).  The last layer (256 -> 3) is a VALU dot product.
+// arithmetic, same bytes: at 4 x 512^2 the backward takes 37 % and the training forward 28 % fewer cycles
+// (profiles/r05_bgmlp_counters.txt), MFMA busy 0.23 / 0.38, and both move their planes at HBM speed.  Inference is its own
+// instantiation (fwd_kernel<false>) with no store code at all.
 //
 // Backward: the same tile walk in reverse for the INPUT gradients (dZ_l = (dZ_{l+1} . W_{l+1}) * leaky'(A_l)), with
 // the transposed weights as B operand; dZ_l is written once as bf16.  Weight and bias gradients are plain
