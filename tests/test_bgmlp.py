@@ -190,3 +190,35 @@ def test_image_groups_do_not_change_the_result():
     for a, b, c in zip(g1, g2, g3):
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-3 * scale and float((a - c).abs().max()) <= 2e-3 * scale
+
+
+def test_grouping_and_train_flag_host_logic(monkeypatch):
+    """Host logic of fused_background_mlp (no kernel runs): under torch.no_grad(), or when nothing requires a gradient, ONE call
+    with train = False (the inference instantiation, whatever the batch size); in training a batch larger than the group size
+    is cut into consecutive image groups, the per-image bias with it, and the pieces are concatenated in order."""
+    from ava256_amd import bgmlp
+    calls = []
+
+    def fake_apply(train, sc, bias1, w1pos, w6, b6, *flat):
+        calls.append((bool(train), sc.shape[0], bias1.shape[0], float(sc[0, 0, 0, 0])))
+        return sc[..., 0][:, None].expand(sc.shape[0], 3, sc.shape[1], sc.shape[2]) + bias1.sum() * 0
+
+    monkeypatch.setattr(bgmlp._FusedBgMlp, "apply", staticmethod(fake_apply))
+    B = 7
+    sc = torch.arange(B, dtype=torch.float32)[:, None, None, None].expand(B, 2, 3, 2).contiguous()
+    bias1 = torch.zeros(B, 256, requires_grad=True)
+    w1pos, w6, b6 = torch.zeros(256, 40), torch.zeros(3, 256), torch.zeros(3)
+    hidden = [(torch.zeros(256, 256), torch.zeros(256)) for _ in range(4)]
+    out = bgmlp.fused_background_mlp(sc, bias1, w1pos, hidden, w6, b6, images_per_call=3)
+    assert calls == [(True, 3, 3, 0.0), (True, 3, 3, 3.0), (True, 1, 1, 6.0)]
+    assert out.shape == (B, 3, 2, 3) and torch.equal(out[:, 0, 0, 0], torch.arange(B, dtype=torch.float32))
+    calls.clear()
+    with torch.no_grad():
+        bgmlp.fused_background_mlp(sc, bias1, w1pos, hidden, w6, b6, images_per_call=3)
+    assert calls == [(False, B, B, 0.0)]
+    calls.clear()
+    bgmlp.fused_background_mlp(sc, bias1.detach(), w1pos, hidden, w6, b6, images_per_call=3)   # nothing requires a gradient
+    assert calls == [(False, B, B, 0.0)]
+    calls.clear()
+    bgmlp.fused_background_mlp(sc[:2], bias1[:2], w1pos, hidden, w6, b6)                        # small batch: one call
+    assert calls == [(True, 2, 2, 0.0)]
