@@ -9,6 +9,7 @@ keep_raysat = False                 # tests: keep the last forward's raysat tens
 last_raysat = None
 last_pl_count = None                # ... and its forward->backward hand-off counters ([N*K] counts, then flags, bounds)
 last_flags_index = 0                # index of the flags word in it (N*K)
+last_handoff_shape = None           # (N, H, W, K, list capacity) of that forward
 
 
 class patched_handoff:

@@ -118,6 +118,10 @@ def fused_background_mlp(samplecoords, bias1, w1pos, hidden, w6, b6, images_per_
     not depend on the grouping; weight gradients are summed over the groups in fp32 by autograd."""
     flat = [t for wb in hidden for t in wb]
     train = torch.is_grad_enabled() and any(t.requires_grad for t in (bias1, w1pos, w6, b6, *flat))
+    # Pixel coordinates are data (mlp2d.py:56-60 receives them from the batch): no gradient is defined for them here.  Detached,
+    # so that a samplecoords tensor that happens to require grad cannot make autograd build a node over an inference-mode
+    # forward (which saves nothing for a backward).
+    samplecoords = samplecoords.detach()
     B = samplecoords.shape[0]
     n = int(images_per_call or IMAGES_PER_CALL)
     if not train or B <= n:

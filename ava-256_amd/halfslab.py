@@ -69,6 +69,22 @@ def _check_half(template_half, N, K):
     return aligned(template_half)
 
 
+def _check_prims(primpos, primrot, primscale, N):
+    """The shape contract of the fp32 operator (mvpraymarch.py: _forward_impl; reference mvpraymarch.py:112-127): one
+    primitive set PER IMAGE.  build_accel sizes the node boxes from primpos.size(0), so a [1,K,..] avatar rendered from N > 1
+    cameras would make the kernel read boxes and poses of images that do not exist."""
+    K = primpos.size(1) if primpos.dim() == 3 else -1
+    assert primpos.shape == (N, K, 3) and primrot.shape == (N, K, 3, 3) and primscale.shape == (N, K, 3), \
+        "primpos / primrot / primscale must be [N,K,3] / [N,K,3,3] / [N,K,3] with N = %d images" % N
+    return K
+
+
+def _same_device(*tensors):
+    devs = {t.device for t in tensors if torch.is_tensor(t)}
+    if len(devs) > 1:
+        raise RuntimeError("all inputs must live on one device, got %s" % sorted(str(d) for d in devs))
+
+
 def _no_grad(*tensors):
     if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
         raise RuntimeError("the half-precision slab path renders only: call it under torch.no_grad() (training keeps fp32 "
@@ -82,10 +98,12 @@ def render_half(raypos, raydir, stepsize, tminmax, primtransf, template_half, fa
     raypos = aligned(require_device_f32("raypos", raypos))
     raydir = aligned(require_device_f32("raydir", raydir))
     tminmax = aligned(require_device_f32("tminmax", tminmax))
+    assert raypos.dim() == 4 and raypos.size(3) == 3
     N, H, W = raypos.size(0), raypos.size(1), raypos.size(2)
-    K = primpos.size(1)
     assert raydir.shape == raypos.shape and tminmax.shape == raypos.shape[:3] + (2,)
+    K = _check_prims(primpos, primrot, primscale, N)
     th = _check_half(template_half, N, K)
+    _same_device(raypos, raydir, tminmax, primpos, primrot, primscale, th)
     dev = primpos.device
     with torch.no_grad():
         _, _, nodeaabb = build_accel((primpos, primrot, primscale), 0, fixedorder=True)
@@ -105,14 +123,18 @@ def render_half_from_cameras(campos, camrot, focal, princpt, pixelcoords, volrad
     _no_grad(campos, camrot, focal, princpt, primpos, primrot, primscale, template_half)
     campos, camrot = require_device_f32("campos", campos), require_device_f32("camrot", camrot)
     focal, princpt = require_device_f32("focal", focal), require_device_f32("princpt", princpt)
-    N, K = campos.size(0), primpos.size(1)
+    N = campos.size(0)
+    assert campos.shape == (N, 3) and camrot.shape == (N, 3, 3) and focal.shape == (N, 2) and princpt.shape == (N, 2)
     if isinstance(pixelcoords, tuple):
         W, H = pixelcoords
         pc = None
     else:
         pc = aligned(require_device_f32("pixelcoords", pixelcoords))
+        assert pc.dim() == 4 and pc.size(0) == N and pc.size(3) == 2
         H, W = pc.size(1), pc.size(2)
+    K = _check_prims(primpos, primrot, primscale, N)
     th = _check_half(template_half, N, K)
+    _same_device(campos, camrot, focal, princpt, pc, primpos, primrot, primscale, th)
     dev = primpos.device
     with torch.no_grad():
         _, _, nodeaabb = build_accel((primpos, primrot, primscale), 0, fixedorder=True)

@@ -63,6 +63,34 @@ _LIST_BYTES_MIN = 64 << 20  # the lists of a call may take this much ...
 _LIST_BYTES_PER_PRIM = 2048  # ... or this much per primitive (a quarter of an 8^3 slab), whichever is more
 
 
+def _budget_clamp(cap, N, K):
+    """The memory budget of the lists: max(64 MiB, 2 KiB per primitive), never below 32 entries."""
+    if N is not None and N * K > 0:
+        budget = max(_LIST_BYTES_MIN, _LIST_BYTES_PER_PRIM * N * K)
+        cap = max(32, min(cap, budget // (8 * N * K) // 8 * 8))
+    return cap
+
+
+def capacity_for_demand(demand, N, K):
+    """The capacity the feedback asks for at a measured demand (no hysteresis): 1.25 x, a multiple of 8 in [32, 2048], inside
+    the memory budget."""
+    return _budget_clamp((int(min(max(32.0, 1.25 * float(demand)), 2048)) + 7) // 8 * 8, N, K)
+
+
+def capacity_wanted_now(pl_count, N, H, W, K):
+    """What capacity would the feedback choose for the counters in `pl_count` (a forward's hand-off words)?  SYNCHRONOUS
+    (histogram launch + 1 KB read-back): for the rare look a captured training graph takes at its frozen capacity
+    (trainloop.Trainer.step).  The measurement is also noted for the shape, so that eager calls that follow size their lists
+    from it at once."""
+    dev = pl_count.device
+    hist = torch.empty(257, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.get_lib().mvp_list_demand(ptr(pl_count), N * K, ptr(hist), stream_ptr(dev)), "mvp_list_demand")
+    wanted = wanted_from_histogram(hist.cpu().tolist())
+    _LIST_DEMAND.setdefault((dev.index, H, W, K), _ListDemand()).note(wanted)
+    return capacity_for_demand(wanted, N, K)
+
+
 def primlist_capacity(H, W, K, device=None, N=None):
     """Per-primitive capacity of the packet lists handed from forward to backward.  First call of a shape: a heuristic
     -- on head-like scenes a packet (8x8 pixels) lists ~19 primitives and ~46 % of the packets hit anything (measured, C2),
@@ -83,10 +111,7 @@ def primlist_capacity(H, W, K, device=None, N=None):
             if st.cap and 0.6 * st.cap <= cap <= st.cap:
                 cap = st.cap
             st.cap = cap
-    if N is not None and N * K > 0:
-        budget = max(_LIST_BYTES_MIN, _LIST_BYTES_PER_PRIM * N * K)
-        cap = max(32, min(cap, budget // (8 * N * K) // 8 * 8))
-    return cap
+    return _budget_clamp(cap, N, K)
 
 
 def note_list_demand(pl_count, N, H, W, K):
@@ -233,6 +258,7 @@ def _forward_impl(ctx, rays, cams, stepsize, primpos, primrot, primscale, templa
         _hooks.last_raysat = raysat
         _hooks.last_pl_count = pl_count
         _hooks.last_flags_index = N * K     # pl_count[N*K] = the flags word (include/mvp_abi.h)
+        _hooks.last_handoff_shape = (N, H, W, K, pl_cap)
     # (camera form in grad mode: raypos / raydir / tminmax are the tensors the forward march has just written)
     ctx.save_for_backward(raypos, raydir, tminmax, nodeaabb, primpos, primrot, primscale, template, raysat, rayaux,
                           pl_count, pl_list, warp)

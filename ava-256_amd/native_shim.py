@@ -75,33 +75,36 @@ STRICT_FIRST_CALLS = 8       # ... as the first calls of a process do anyway, an
 _ORDER_PENDING = []          # [(event, pinned word, weakref(tensor), version)]: device-side checks not yet looked at
 _ORDER_CALLS = [0]           # content checks enqueued so far
 _ARANGE = {}                 # (device index, K, dtype) -> arange(K)
+_VERIFIED = {}               # (device index, K, dtype) -> verdicts "identity" read so far for that kind of tensor
 _BAD_ORDER = ("sortedobjid of %s raymarch call is not the fixed identity order (its results are in the wrong composition "
               "order): only usebvh='fixedorder' without randomorder is supported")
 
 
-def _poll_order_checks(wait=False, current=False):
+def _poll_order_checks(wait=False, current=None):
     """Look at the device-side verdicts that have arrived (all of them with wait=True).  A tensor is marked as checked only
     HERE, once its verdict has been read as "identity" -- never before the verdict is known, so a caller that catches the
     error and hands the same bad tensor in again is refused again.  Raises for a bad order; the other pending verdicts stay
     queued.  Called from the forward and backward shims (host thread and autograd thread): the list is swapped, not edited in
     place, and a verdict looked at twice is harmless."""
-    pending, bad, keep = list(_ORDER_PENDING), False, []
+    pending, bad, bad_current, keep = list(_ORDER_PENDING), False, False, []
     for item in pending:
-        ev, word, ref, ver = item
+        ev, word, ref, ver, key = item
         if wait:
             ev.synchronize()
         if ev.query():
             if int(word[0]) != 0:
                 bad = True
+                bad_current = bad_current or item is current
             else:
+                _VERIFIED[key] = _VERIFIED.get(key, 0) + 1
                 t = ref()
                 if t is not None and t._version == ver:
                     t._mvp_identity = ver
         else:
             keep.append(item)
     _ORDER_PENDING[:] = keep + [i for i in _ORDER_PENDING if i not in pending]
-    if bad:
-        raise NotImplementedError(_BAD_ORDER % ("this" if current and wait else "an EARLIER"))
+    if bad:   # (`current` = the check the calling shim has just queued: the message says whose tensor it was)
+        raise NotImplementedError(_BAD_ORDER % ("this" if bad_current else "an EARLIER"))
 
 
 def flush_order_checks():
@@ -115,9 +118,12 @@ def _identity_order(sortedobjid, K, strict=False):
     """usebvh='fixedorder' hands arange(K) per image (mvpraymarch.py:45); any other order (randomorder=True, the LBVH
     path) would silently render in the wrong composition order here.  Shape errors raise at once.  The CONTENT is compared
     on the device; WHEN the one-word verdict is read depends on who is calling:
-      * a call without gradients (a render / evaluation: possibly the only call there is), the first STRICT_FIRST_CALLS
-        calls of the process, and everything under STRICT_ORDER_CHECK wait for it inside the call -- the offending call
-        itself fails, before its image can be used;
+      * the first STRICT_FIRST_CALLS calls of the process, everything under STRICT_ORDER_CHECK, and a call without gradients
+        (a render / evaluation: possibly the only call there is) UNTIL STRICT_FIRST_CALLS verdicts "identity" have been read
+        for tensors of its kind (device, K, dtype) wait for it inside the call -- the offending call itself fails, before its
+        image can be used.  After that a render loop is treated like a training loop: the reference's glue makes a new
+        sortedobjid per forward (mvpraymarch.py:45), so a per-tensor cache can never hit and waiting would cost every render a
+        host synchronisation; `flush_order_checks()` is there for a caller that wants the verdict before using an image;
       * a training step (the reference's glue builds a NEW sortedobjid on every forward, so the check runs on every call
         and must not block the host) leaves the verdict behind an event; the backward of the same step and the next calls
         look at it.  An order policy is a constant of a run, so a wrong one has failed within the strict first calls.
@@ -138,10 +144,12 @@ def _identity_order(sortedobjid, K, strict=False):
     word.copy_((sortedobjid != ar[None]).any().to(torch.int32).reshape(1), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    _ORDER_PENDING.append((ev, word, weakref.ref(sortedobjid), sortedobjid._version))
+    item = (ev, word, weakref.ref(sortedobjid), sortedobjid._version, key)
+    _ORDER_PENDING.append(item)
     _ORDER_CALLS[0] += 1
-    if strict or STRICT_ORDER_CHECK or _ORDER_CALLS[0] <= STRICT_FIRST_CALLS or len(_ORDER_PENDING) > 64:
-        _poll_order_checks(wait=True, current=True)
+    if ((strict and _VERIFIED.get(key, 0) < STRICT_FIRST_CALLS) or STRICT_ORDER_CHECK or _ORDER_CALLS[0] <= STRICT_FIRST_CALLS
+            or len(_ORDER_PENDING) > 64):
+        _poll_order_checks(wait=True, current=item)
 
 
 def compute_morton(*args):

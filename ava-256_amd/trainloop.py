@@ -652,7 +652,11 @@ class Trainer:
             out = self._iteration(batch, schedule)
             self._advance()
             return out
-        key = tuple(sorted(schedule.items()))
+        # The graph is the iteration of ONE schedule over ONE batch layout: tensor shapes and the non-tensor entries (a (W, H)
+        # pixelcoords tuple) are frozen into it, so they are part of the key -- another layout gets its own graph instead of a
+        # silent replay of the captured one (or a broadcasting copy_).
+        key = (tuple(sorted(schedule.items())),
+               tuple(sorted((k, tuple(v.shape) if torch.is_tensor(v) else repr(v)) for k, v in batch.items())))
         st = self._graphs.get(key)
         if st is None:
             seen = self._eager_seen.get(key, 0)
@@ -669,17 +673,30 @@ class Trainer:
         st["graph"].replay()
         self.graph_replays += 1
         st["replays"] += 1
-        if st["handoff"] is not None and st["replays"] % self.graph_check_every == 0:
+        if st["handoff"] is not None and st["replays"] >= st["next_check"]:
             # The graph froze the march's primitive-list capacity of the moment it was captured (the operators skip their
             # demand feedback while capturing and on replay).  If primitive footprints have grown since, primitives over that
             # capacity sit on the slow ray-centric backward for the rest of the graph's life: look at the forward's overflow
-            # flag now and then (one 4-byte read-back) and, when it is raised, drop the graph -- the next iterations run eagerly
-            # (their feedback re-sizes the lists) and a new graph is captured.
-            pl_count, nk = st["handoff"]
-            if int(pl_count[nk].item()) & 1:          # kFlagListOverflow (csrc/march_common.h)
+            # flag now and then (one 4-byte read-back).  The flag alone is no reason to re-capture: the capacity policy itself
+            # leaves it raised for good in three cases (an outlier clipped to 2 x the 99.9th percentile, the memory budget, the
+            # cap of 2048 -- mvpraymarch.wanted_from_histogram / primlist_capacity), and a new graph would carry the same
+            # capacity.  So ask what the feedback would choose for the counters of THIS replay; only a larger capacity drops
+            # the graph (the next iterations run eagerly, their lists sized from the measurement just noted, and a new graph
+            # is captured); otherwise the interval between looks doubles.
+            pl_count, nk, (hn, hh, hw, hk, hcap) = st["handoff"]
+            flagged = bool(int(pl_count[nk].item()) & 1)          # kFlagListOverflow (csrc/march_common.h)
+            recapture = False
+            if flagged:
+                from .mvpraymarch import capacity_wanted_now
+                recapture = capacity_wanted_now(pl_count, hn, hh, hw, hk) > hcap
+            if recapture:
                 del self._graphs[key]
                 self._eager_seen[key] = 0
                 self.graph_recaptures += 1
+            else:
+                if flagged:   # raised by the policy's own clipping: nothing a new capture would change -- look less often
+                    st["check_every"] = min(2 * st["check_every"], 1 << 16)
+                st["next_check"] = st["replays"] + st["check_every"]
         self.last_grad_norm = st["norm"]
         self._advance()
         return st["loss"], st["parts"]
@@ -703,11 +720,12 @@ class Trainer:
                 norm = self.last_grad_norm
             handoff = None
             if _hooks.last_pl_count is not None:   # the captured forward's counters + flags word (a tensor of the graph's pool)
-                handoff = (_hooks.last_pl_count, _hooks.last_flags_index)
+                handoff = (_hooks.last_pl_count, _hooks.last_flags_index, _hooks.last_handoff_shape)
         finally:
             _hooks.keep_raysat, _hooks.last_raysat, _hooks.last_pl_count = keep, None, None
         # the capture itself ran nothing: the first replay is this iteration
-        return {"graph": g, "in": static_in, "loss": loss, "parts": parts, "norm": norm, "handoff": handoff, "replays": 0}
+        return {"graph": g, "in": static_in, "loss": loss, "parts": parts, "norm": norm, "handoff": handoff, "replays": 0,
+                "check_every": self.graph_check_every, "next_check": self.graph_check_every}
 
 
 @torch.no_grad()

@@ -222,3 +222,11 @@ def test_grouping_and_train_flag_host_logic(monkeypatch):
     calls.clear()
     bgmlp.fused_background_mlp(sc[:2], bias1[:2], w1pos, hidden, w6, b6)                        # small batch: one call
     assert calls == [(True, 2, 2, 0.0)]
+    calls.clear()
+    # pixel coordinates that require grad (and nothing else does): they are data here -- the call sees them detached and runs
+    # the inference instantiation; autograd builds no node over a forward that saved nothing (advisor, round 5)
+    seen = []
+    monkeypatch.setattr(bgmlp._FusedBgMlp, "apply", staticmethod(lambda train, sc_, *a: (seen.append(sc_.requires_grad),
+                                                                                        fake_apply(train, sc_, *a))[1]))
+    out = bgmlp.fused_background_mlp(sc.clone().requires_grad_(True), bias1.detach(), w1pos, hidden, w6, b6)
+    assert calls == [(False, B, B, 0.0)] and seen == [False] and not out.requires_grad

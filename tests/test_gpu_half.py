@@ -187,3 +187,32 @@ def test_half_path_refuses_gradients_and_other_slab_sizes(ops):
             halfslab.render_half_from_cameras(*args, prim, d["template"])
         with pytest.raises(NotImplementedError):
             halfslab.render_half_from_cameras(*args, prim, torch.zeros(1, 8, 4, 4, 4, 4, device="cuda", dtype=torch.float16))
+
+
+def test_half_path_checks_shapes_like_the_fp32_operator(ops):
+    """One avatar ([1,K,..] primitives) rendered from N > 1 cameras must be refused, as mvpraymarch refuses it
+    (mvpraymarch.py:112-127): the node boxes are sized from primpos.size(0) and the kernel would read past them."""
+    from ava256_amd import halfslab
+    s = _scene(2, 16, 16, 8, 1.0)
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in s.items()}
+    th = halfslab.template_to_half(d["template"])
+    cam = (d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"], d["stepsize"])
+    one = (d["primpos"][:1], d["primrot"][:1], d["primscale"][:1])
+    with torch.no_grad():
+        halfslab.render_half_from_cameras(*cam, (d["primpos"], d["primrot"], d["primscale"]), th)
+        with pytest.raises(AssertionError):
+            halfslab.render_half_from_cameras(*cam, one, th)
+        with pytest.raises(AssertionError):
+            halfslab.render_half_from_cameras(*cam, one, th[:1])
+        with pytest.raises(AssertionError):   # rotation given as [N,K,9]
+            halfslab.render_half_from_cameras(*cam, (d["primpos"], d["primrot"].reshape(2, -1, 9), d["primscale"]), th)
+        with pytest.raises(AssertionError):   # pixel coordinates of another batch size
+            halfslab.render_half_from_cameras(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"][:1],
+                                              d["volradius"], d["stepsize"], (d["primpos"], d["primrot"], d["primscale"]), th)
+        rp, rd, tm = ops.compute_raydirs(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"])
+        halfslab.render_half(rp, rd, d["stepsize"], tm, (d["primpos"], d["primrot"], d["primscale"]), th)
+        with pytest.raises(AssertionError):
+            halfslab.render_half(rp, rd, d["stepsize"], tm, one, th[:1])
+        with pytest.raises(AssertionError):
+            halfslab.render_half(rp.reshape(2, -1, 3), rd.reshape(2, -1, 3), d["stepsize"], tm.reshape(2, -1, 2),
+                                 (d["primpos"], d["primrot"], d["primscale"]), th)

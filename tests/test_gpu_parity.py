@@ -580,8 +580,27 @@ def test_drop_in_boundary_matches_reference_glue(ops):
             else:
                 assert cosine(got, ref) >= 0.9999, k
                 assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max(), k
-    else:  # (not expected for this fixture) compare on the agreeing rays through the oracle instead
-        pytest.skip("saturation state differs on some rays: gradient comparison needs the masked loss")
+    else:
+        # (not expected for this fixture) some ray saturates in one arithmetic and not in the other: the fixture's gradients
+        # belong to the unmasked loss, so the comparison runs on the agreeing rays against the float64 oracle marched on the
+        # fixture's own rays with the same options -- a masked loss on both sides, never a skip
+        from oracle.mvp_oracle import Oracle
+        o64 = Oracle("f64")
+        a = (g["raypos"], g["raydir"], float(g["dt"]) / volradius, g["tminmax"], g["in_primpos"], g["in_primrot"],
+             g["in_primscale"], g["in_template"])
+        ref_rgba, ref_sat, _ = o64.march_forward(*a, fadescale=6.0, fadeexp=8.0)
+        assert np.abs(ref_rgba[..., :3].transpose(0, 3, 1, 2) - g["rayrgb"]).max() <= 1e-9 * max(1.0, np.abs(g["rayrgb"]).max())
+        gout = np.ascontiguousarray(np.concatenate([g["w_rgb"], g["w_a"]], axis=1).transpose(0, 2, 3, 1) * (sat_ref == sat_here)[..., None])
+        rgp, rgr, rgs, rgt = o64.march_backward(*a, ref_sat, gout, fadescale=6.0, fadeexp=8.0)
+        loss = ((rayrgb * w_rgb).sum(1, keepdim=True) * agree).sum() + (rayalpha * w_a * agree).sum()
+        loss.backward()
+        for k, ref in (("template", rgt), ("primpos", rgp), ("primrot", rgr), ("primscale", rgs)):
+            got = npf(decout[k].grad)
+            if k == "template":
+                assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), k
+            else:
+                assert cosine(got, ref) >= 0.9999, k
+                assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max(), k
     mm.keep_raysat = False
 
 

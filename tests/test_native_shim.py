@@ -167,9 +167,11 @@ def test_shim_order_check():
         return rgba
 
     ns.flush_order_checks()
+    ns._VERIFIED.clear()
     ident = lambda: (torch.arange(N * K, dtype=torch.int32, device=dev) % K).view(N, K)
     perm = ident().flip(1).contiguous()
-    # (1) without gradients the offending call itself fails, every time, also past the strict first calls
+    # (1) without gradients the offending call itself fails, every time, also past the strict first calls -- as long as fewer
+    #     than STRICT_FIRST_CALLS identity verdicts have been read for tensors of this kind
     ns._ORDER_CALLS[0] = ns.STRICT_FIRST_CALLS + 100
     for _ in range(2):
         with pytest.raises(NotImplementedError, match="this raymarch call"):
@@ -197,3 +199,20 @@ def test_shim_order_check():
     ns._ORDER_CALLS[0] = ns.STRICT_FIRST_CALLS + 100
     with pytest.raises(NotImplementedError):
         fwd(ident()[:, : K // 2].contiguous())
+    # (4) a render LOOP (the reference's glue hands a new sortedobjid to every forward, so no per-tensor cache can hit): once
+    #     STRICT_FIRST_CALLS identity verdicts have been read for this kind of tensor, a call without gradients no longer waits
+    #     inside the call; a wrong order is then reported by the next call or by flush_order_checks(), and says whose it was
+    ns.flush_order_checks()
+    ns._VERIFIED.clear()
+    for _ in range(ns.STRICT_FIRST_CALLS):
+        fwd(ident())                                             # each waits for its verdict inside the call
+    assert sum(ns._VERIFIED.values()) == ns.STRICT_FIRST_CALLS and not ns._ORDER_PENDING
+    fwd(ident())
+    assert len(ns._ORDER_PENDING) == 1                           # deferred: nobody waited
+    ns.flush_order_checks()
+    fwd(ident().flip(1).contiguous())                            # a bad order now passes the call itself ...
+    torch.cuda.synchronize()
+    with pytest.raises(NotImplementedError, match="EARLIER"):
+        fwd(ident())                                             # ... and the next call reports it
+    ns.flush_order_checks()
+    ns._VERIFIED.clear()

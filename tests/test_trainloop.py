@@ -377,3 +377,47 @@ def test_graph_replay_trains_like_the_eager_loop():
     for a, b in zip(pe, pg):
         assert (a - b).abs().max().item() <= 1e-3 * 12 * 1e-3 + 1e-6 * a.abs().max().item()
     assert torch.isfinite(tg.last_grad_norm).all()
+
+
+@pytest.mark.gpu
+def test_graph_is_recaptured_only_when_a_new_capture_would_get_larger_lists(monkeypatch):
+    """The captured iteration freezes the primitive-list capacity.  A raised list-overflow flag drops the graph only when
+    the capacity feedback would NOW choose a larger capacity than the captured one; a flag the capacity policy itself leaves
+    raised for good (outlier clipping, memory budget, the cap of 2048) must not cost a re-capture every 64 replays -- the
+    interval between looks doubles instead (advisor, round 5)."""
+    import importlib
+    mm = importlib.import_module("ava256_amd.mvpraymarch")   # (the package re-exports a FUNCTION of that name)
+    from ava256_amd.trainloop import (CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel, SlabDecoderStandIn, Trainer,
+                                      make_training_batch)
+    dev = "cuda"
+    batch, volradius = make_training_batch(2, 64, 64, 256, dev, seed=5, target_decoder=SlabDecoderStandIn(256, seed=9))
+    torch.manual_seed(0)
+    model = RaymarchTrainModel(SlabDecoderStandIn(256, seed=1), volradius, colorcal=ColorCalStandIn(80, 4),
+                               encoder=CodeEncoderStandIn()).to(dev)
+    tr = Trainer(model, lr=1e-3, graph=True, graph_warmup=2)
+    tr.graph_check_every = 2
+    real_capacity, real_wanted = mm.primlist_capacity, mm.capacity_wanted_now
+    monkeypatch.setattr(mm, "primlist_capacity", lambda H, W, K, device=None, N=None: 4)   # lists far below the demand
+    for _ in range(3):                       # two eager iterations, then the capture (its first replay)
+        tr.step(batch)
+    (st,) = tr._graphs.values()
+    pl_count, nk, shape = st["handoff"]
+    assert shape == (2, 64, 64, 256, 4) and int(pl_count[nk].item()) & 1, "the scene must overflow lists of 4 entries"
+    # (a) the policy would choose the same capacity again: no re-capture, and the looks thin out
+    monkeypatch.setattr(mm, "capacity_wanted_now", lambda *a: 4)
+    for _ in range(12):
+        tr.step(batch)
+    assert tr.graph_recaptures == 0 and len(tr._graphs) == 1 and st["check_every"] >= 8
+    # (b) the policy would choose a larger capacity: the graph is dropped at the next look, the eager iterations size their
+    # lists from the measurement that look has noted, and the new graph's forward no longer overflows
+    monkeypatch.setattr(mm, "capacity_wanted_now", real_wanted)
+    monkeypatch.setattr(mm, "primlist_capacity", real_capacity)
+    for _ in range(st["check_every"] + 1):
+        tr.step(batch)
+    assert tr.graph_recaptures == 1
+    for _ in range(4):
+        tr.step(batch)
+    (st2,) = tr._graphs.values()
+    pl2, nk2, shape2 = st2["handoff"]
+    assert shape2[4] > 4 and (int(pl2[nk2].item()) & 1) == 0
+    assert np.isfinite(float(tr.step(batch)[0]))

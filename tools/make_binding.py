@@ -34,6 +34,11 @@ d = [
     ("wave_time: of which stalled on LDS issue (SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES)", c["SQ_WAIT_INST_LDS"] / c["SQ_WAVE_CYCLES"]),
     ("VALU_insts_per_LDS_inst", c["SQ_INSTS_VALU"] / c["SQ_INSTS_LDS"]),
 ]
+if "SQ_THREAD_CYCLES_VALU" in c:   # (round 6) both counters tick in the same unit: a kernel with every lane on reads 1.000 (raydirs_kernel)
+    d.append(("VALU_lane_utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))",
+              c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])))
+    d.append(("VALU_issue_ceiling_ms (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs at 2.4 GHz: the kernel if nothing but its VALU "
+              "instructions took time)", c["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e6))
 with open(out, "w") as f:
     w = csv.writer(f)
     w.writerow(["quantity", "value"])

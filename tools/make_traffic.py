@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/make_traffic.py <fetch_summary.csv> <write_summary.csv> [workload [sq_summary.csv lds_summary.csv]] -- derive profiles/traffic.json (per-launch HBM
+"""tools/make_traffic.py <fetch_summary.csv> <write_summary.csv> [workload [sq_summary.csv lds_summary.csv]] -- workload = C2
+(default), C3, C4 or C2_saturated (the same C2 step at opacity x 40: bench.py's `saturated` leg).  Derive profiles/traffic.json (per-launch HBM
 bytes of the march kernels, read by bench.py for `roofline.traffic`) from the two separate rocprofv3 --pmc passes that
 tools/pmc.sh summarised, and STAMP it with the commit the passes were measured at (run this in the build container
 right after the gpurun call returned, before the kernels change again).  bench.py prints the stamp next to the number.
@@ -43,8 +44,13 @@ def main():
     doc = json.load(open(tf)) if os.path.exists(tf) else {}
     doc["_how"] = ("per-launch HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate --pmc passes (per-dispatch "
                    "averages of the march kernels; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'); tools/make_traffic.py")
-    doc["_measured_at_commit"] = head + ("+uncommitted kernel changes" if dirty else "")
-    doc["_sources"] = [os.path.relpath(os.path.abspath(p), ROOT) for p in (fetch, write)]
+    stamp = head + ("+uncommitted kernel changes" if dirty else "")
+    srcs = [os.path.relpath(os.path.abspath(p), ROOT) for p in (fetch, write)]
+    if workload == "C2":   # the headline workload keeps the top-level stamp the bench line prints
+        doc["_measured_at_commit"] = stamp
+        doc["_sources"] = list(srcs)
+    # (round 6) every workload carries its own stamp and sources: C3 / C4 / "C2_saturated" are separate passes
+    doc.setdefault("_by_workload", {})[workload] = {"measured_at_commit": stamp, "sources": srcs}
     doc[workload] = {k: (2.0 * f[k] + w[k]) * 1024.0 for k in sorted(f) if k in w}
     if len(sys.argv) > 5:
         sq, lds = sys.argv[4], sys.argv[5]
@@ -54,7 +60,10 @@ def main():
         doc.setdefault("valu", {})[workload] = {
             k: {"wave_insts": insts[k], "busy": active[k] * 4.0 / (1024.0 * cyc[k]), "wait": wait[k] / wcyc[k],
                 "kernel_cycles": cyc[k]} for k in sorted(insts) if k in active and k in cyc and k in wcyc and k in wait}
-        doc["_sources"] += [os.path.relpath(os.path.abspath(p), ROOT) for p in (sq, lds)]
+        more = [os.path.relpath(os.path.abspath(p), ROOT) for p in (sq, lds)]
+        doc["_by_workload"][workload]["sources"] += more
+        if workload == "C2":
+            doc["_sources"] += more
     json.dump(doc, open(tf, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
