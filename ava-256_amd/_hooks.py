@@ -31,7 +31,7 @@ class patched_handoff:
             if ray_centric:
                 return None, None, None, 0
             rayaux, pl_count, _, _ = self._orig(N, H, W, K, dev)
-            return rayaux, pl_count, torch.empty((N * K, cap, 2), device=dev, dtype=torch.int32), cap
+            return rayaux, pl_count, torch.empty((N * K, cap, m.LIST_ENTRY_WORDS), device=dev, dtype=torch.int32), cap
 
         if cap is not None or ray_centric:
             m.alloc_handoff = alloc

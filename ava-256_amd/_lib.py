@@ -79,7 +79,7 @@ SIGNATURES["mvp_pixel_tail_blocks"] = (_c_int, [_c_int] * 2)
 SIGNATURES["mvp_pixel_tail_forward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 8 + [_c_void_p])
 # N,H,W | rayrgba,cw,bg,target,irgbrec,g_irgbrec,g_ialpha,g_l1 | grad_rayrgba,grad_bg,cwcb_partials | stream
 SIGNATURES["mvp_pixel_tail_backward"] = (_c_int, [_c_int] * 3 + [_c_void_p] * 11 + [_c_void_p])
-ABI_VERSION = 15
+ABI_VERSION = 17
 DIAG_WORDS = 8
 DIAG_NAMES = ["frontier_overflow", "list_overflow", "slowpath_packets", "max_list", "packets_hit", "list_entries",
               "candidates"]

@@ -225,7 +225,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             tv[i] = (tid + i * kPrimBlock < 512) ? MVP_STREAM_LOAD(T4 + tid + i * kPrimBlock) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 *gT4 = reinterpret_cast<float4 *>(p.grad_tplate) + pk * (size_t)V;
-    const uint2 *list = p.pl_list + pk * (size_t)p.pl_cap;
+    const uint4 *list = p.pl_list + pk * (size_t)p.pl_cap;  // {key, step range, ray mask lo, hi} per entry
     bool dead = (flags & kFlagGlobal) != 0u || cnt > (uint32_t)p.pl_cap;  // the ray-centric kernel owns it
     // ... and marches only the packets somebody asked it to: the ones the forward could not append are marked already,
     // the recorded ones are marked here, by whoever hands a primitive over
@@ -350,14 +350,14 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         // stream is wave-uniform -> scalar loads, four entries (32 bytes; pl_cap is a multiple of 4) at a time
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: HIP's uint4 class has no
         typedef const __attribute__((address_space(4))) u32x4 *cu4;   //  constructor from another address space)
-        const cu4 l4 = reinterpret_cast<cu4>(reinterpret_cast<uintptr_t>(list));
+        const cu4 l4 = reinterpret_cast<cu4>(reinterpret_cast<uintptr_t>(list));   // one entry per 16-byte element
         for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
             const uint32_t key = list[e].x;
             uint32_t rank = 0u;
             for (uint32_t j = 0; j < cnt; j += 4u) {
-                const u32x4 a = l4[j >> 1], b = l4[(j >> 1) + 1];
-                rank += (a.x < key ? 1u : 0u) + ((j + 1u < cnt && a.z < key) ? 1u : 0u) +
-                        ((j + 2u < cnt && b.x < key) ? 1u : 0u) + ((j + 3u < cnt && b.z < key) ? 1u : 0u);
+                const uint32_t k0 = l4[j].x, k1 = l4[j + 1u].x, k2 = l4[j + 2u].x, k3 = l4[j + 3u].x;
+                rank += (k0 < key ? 1u : 0u) + ((j + 1u < cnt && k1 < key) ? 1u : 0u) +
+                        ((j + 2u < cnt && k2 < key) ? 1u : 0u) + ((j + 3u < cnt && k3 < key) ? 1u : 0u);
             }
             s_perm[rank] = (uint16_t)e;
         }
@@ -419,35 +419,72 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                        "+s"(q.r1.x), "+s"(q.r1.y), "+s"(q.r1.z), "+s"(q.r2.x), "+s"(q.r2.y), "+s"(q.r2.z),
                        "+s"(q.scale.x), "+s"(q.scale.y), "+s"(q.scale.z));
         // ---------------- phase 1: which rays of these packets cross the box, and over which steps ----------------
-        // Each wave owns up to kEntriesPerWave entries of the round; a live ray takes a ticket in the bucket of its step count
-        // (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the
-        // 64 rays a wave marches together have (nearly) the same number of steps.
+        // Each wave owns up to kEntriesPerWave entries of the round.  An entry names a ray packet and (round 6) carries the mask
+        // of the packet's rays that have a lattice step in this box by the FORWARD's exact test -- ~40 % of them on head-like
+        // scenes.  The wave first COMPACTS the rays its entries name into one dense sequence (scalar popcount prefix per entry,
+        // v_mbcnt inside it; the records go through this wave's part of the ray queue, which is free until the barrier below),
+        // then examines them 64 at a time: exact interval with the formulas of the forward, clipped to the packet's range and
+        // the ray's first step -- ~2 passes instead of one per entry at C2.  A live ray takes a ticket in the bucket of its step
+        // count (LDS integer atomic), buckets are prefix-summed, and the ray is written at its sorted position, so the 64 rays
+        // a wave marches together have (nearly) the same number of steps.
         const uint32_t eend = min(cnt, ebase + epr);
         uint2 item[kEntriesPerWave];  // {ray index inside the image | list slot << 23, first step | steps << 16}
         uint32_t ticket[kEntriesPerWave];
         bool live2[kEntriesPerWave];
         bool toolong = false;
         uint32_t mylen = 0u;
-        uint32_t gq_hi = 0u;  // bits of the largest max |grad_rayrgba| over the packets this wave queued rays of (wave-uniform)
+        uint32_t gq_hi = 0u;  // bits of the largest max |grad_rayrgba| over the packets this wave examines rays of (wave-uniform)
+        uint32_t ncmp = 0u;   // rays named by this wave's entries (wave-uniform, <= kEntriesPerWave * 64)
+        uint2 *s_cmp = s_q + wave * (kEntriesPerWave * 64);
+        {
+            // the wave's entries (scalar loads, 16 bytes each).  (Round 6 also measured them as ONE batch of unconditional loads
+            // with the packets' gradient bounds behind them -- one wait instead of a dependent round trip per entry: C2 +0.5 %,
+            // C3 +2 % SLOWER, 14 more spilled SGPRs: profiles/r06_backward_experiments.json)
+            uint32_t ekey[kEntriesPerWave], erg[kEntriesPerWave], emlo[kEntriesPerWave], emhi[kEntriesPerWave];
+#pragma unroll
+            for (int u = 0; u < kEntriesPerWave; ++u) {
+                const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
+                ekey[u] = erg[u] = emlo[u] = emhi[u] = 0u;
+                if (e < eend) {
+                    const uint32_t le = multi ? (uint32_t)uni((int)s_perm[e]) : e;
+                    const uint32_t *lw = reinterpret_cast<const uint32_t *>(list + le);  // wave-uniform: scalar loads
+                    ekey[u] = cload(lw), erg[u] = cload(lw + 1), emlo[u] = cload(lw + 2), emhi[u] = cload(lw + 3);
+                }
+            }
+            const uint32_t laneoff = (uint32_t)(lane >> 3) * (uint32_t)p.W + (uint32_t)(lane & 7);
+#pragma unroll
+            for (int u = 0; u < kEntriesPerWave; ++u) {
+                const unsigned long long m = ((unsigned long long)emhi[u] << 32) | emlo[u];
+                if (m != 0ull) {  // (wave-uniform; an entry past the round's end has an empty mask)
+                    const int tidx = (int)(ekey[u] >> 9);
+                    const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
+                    // (the mask names rays inside the image only: the forward's `active`)
+                    const uint32_t rbase = (uint32_t)(ty * kTile) * (uint32_t)p.W + (uint32_t)(tx * kTile);
+                    gq_hi = max(gq_hi, (cload(pmax_n + tidx) & kPacketMaxMask) << 2);
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi(emhi[u], __builtin_amdgcn_mbcnt_lo(emlo[u], ncmp));
+                    if ((m >> lane) & 1ull) s_cmp[pos] = make_uint2((rbase + laneoff) | ((ekey[u] & 511u) << 23), erg[u]);
+                    ncmp += (uint32_t)__popcll(m);
+                }
+            }
+        }
+        // (the records are read back by other lanes of the SAME wave: LDS operations of a wave complete in order, so all it
+        //  takes is that the compiler keeps the order too)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int u = 0; u < kEntriesPerWave; ++u) {
-            const uint32_t e = ebase + wave + u * (kPrimBlock / kWave);
             live2[u] = false;
             ticket[u] = 0u;
             item[u] = make_uint2(0u, 0u);
-            if (e < eend) {
-                const uint32_t le = multi ? (uint32_t)uni((int)s_perm[e]) : e;
-                const uint32_t *lw = reinterpret_cast<const uint32_t *>(list + le);  // wave-uniform: scalar loads
-                const uint2 ent = make_uint2(cload(lw), cload(lw + 1));
-                const int tidx = (int)(ent.x >> 9);
-                const uint32_t slot = ent.x & 511u;
-                const int elo = (int)(ent.y & 0xffffu), ehi = (int)(ent.y >> 16);
-                const int ty = tidx / p.tiles_x, tx = tidx - ty * p.tiles_x;
-                const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
-                const bool inimg = px < p.W && py < p.H;
-                const uint32_t r = inimg ? (uint32_t)py * (uint32_t)p.W + (uint32_t)px : 0u;  // index inside image n
+            if ((uint32_t)(u * kWave) < ncmp) {  // (wave-uniform) pass u over the compacted rays
+                const uint32_t ci = (uint32_t)(u * kWave + lane);
+                const bool have = ci < ncmp;
+                const uint2 cr = have ? s_cmp[ci] : make_uint2(0u, 0u);
+                const uint32_t r = cr.x & 0x7fffffu, slot = cr.x >> 23;  // ray index inside image n, list slot
+                const int elo = (int)(cr.y & 0xffffu), ehi = (int)(cr.y >> 16);
                 int slo = 1, shi = 0;
-                if (inimg) {
+                if (have) {
                     // byte offsets computed in 32 bits: "SGPR base + zero-extended VGPR offset" addressing
                     const f3 o = ld3(at_bytes<float>(raypos_n, r * 12u)), d = ld3(at_bytes<float>(raydir_n, r * 12u));
                     const float2 tt = *at_bytes<float2>(tminmax_n, r * 8u);
@@ -465,7 +502,6 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                         shi = min(h0, ehi);
                     }
                 }
-                if (__ballot(slo <= shi) != 0ull) gq_hi = max(gq_hi, (cload(pmax_n + tidx) & kPacketMaxMask) << 2);
                 if (slo <= shi) {
                     // at most 127 steps per queued item (the len field and the buckets assume short crossings); a box
                     // that is deeper than that along some ray is handed to the ray-centric kernel (flagged below)
@@ -918,9 +954,10 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     }
     // ---- pose gradients: 12 sums per lane -> wave -> workgroup (primtransf.h:155-179) ----
     {
-        const float sums[12] = {wave_sum(a0),  wave_sum(a1),  wave_sum(a2),  wave_sum(c00), wave_sum(c01), wave_sum(c02),
-                                wave_sum(c10), wave_sum(c11), wave_sum(c12), wave_sum(c20), wave_sum(c21), wave_sum(c22)};
-        if (lane == 0) {
+        // (all 64 lanes are enabled here: workgroup-uniform control flow; lanes without rays hold zeros)
+        float sums[12] = {a0, a1, a2, c00, c01, c02, c10, c11, c12, c20, c21, c22};
+        wave_sum12_lane63(sums);
+        if (lane == 63) {
 #pragma unroll
             for (int j = 0; j < 12; ++j) s_red[wave * 12 + j] = sums[j];
         }
@@ -1085,7 +1122,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     p.grad_primpos = grad_primpos, p.grad_primrot = grad_primrot, p.grad_primscale = grad_primscale;
     p.grad_tplate = grad_tplate, p.diag = diag;
     p.rayaux = const_cast<uint32_t *>(rayaux), p.pl_count = primlist_count;
-    p.pl_list = reinterpret_cast<uint2 *>(const_cast<uint32_t *>(primlist)), p.pl_cap = primlist_cap;
+    p.pl_list = reinterpret_cast<uint4 *>(const_cast<uint32_t *>(primlist)), p.pl_cap = primlist_cap;
     int rc = march_common_checks(true, p);
     if (rc == 1) rc = MVP_OK;  // no rays: the gradients are still defined (all zero) -> fall through to the fill
     if (rc != MVP_OK) return rc;

@@ -90,7 +90,8 @@ struct MarchParams {
     uint32_t *rayaux;     // [N,H,W,4]: {satkey, bits(alpha before the saturating sample), first step, bits(tend)}
     uint32_t *pl_count;   // [N*K + 3 + N*tiles]: packets appended per primitive; flags (kFlag*), reserved, bits(Rmax);
                           // then per ray packet bits(max |grad_rayrgba|) of the current backward
-    uint2 *pl_list;       // [N*K, pl_cap]: {(packet << 9) | list slot, lo | hi << 16}
+    uint4 *pl_list;       // [N*K, pl_cap]: {(packet << 9) | list slot, lo | hi << 16, ray mask lo, ray mask hi}: the packet's
+                          // step range in the primitive and which of its 64 rays have a lattice step there (round 6)
     int pl_cap;
     int fallback_all;     // backward: 1 = the ray-centric kernel handles every primitive
     int prim_lds_base;    // bwd_prim_kernel<.., WARP>: byte offset of the warp-field arrays in its dynamic LDS

@@ -38,7 +38,7 @@ static int march_forward_impl(int N, int H, int W, int K, const float *raypos, c
     p.raypos = raypos, p.raydir = raydir, p.tminmax = tminmax, p.nodeaabb = nodeaabb;
     p.primpos = primpos, p.primrot = primrot, p.primscale = primscale, p.tplate = tplate;
     p.rayrgba = rayrgba, p.raysat = raysat, p.diag = diag;
-    p.rayaux = rayaux, p.pl_count = primlist_count, p.pl_list = reinterpret_cast<uint2 *>(primlist);
+    p.rayaux = rayaux, p.pl_count = primlist_count, p.pl_list = reinterpret_cast<uint4 *>(primlist);
     p.pl_cap = primlist_cap;
     int rc = march_common_checks(false, p);
     if (rc == 1) return MVP_OK;

@@ -267,6 +267,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     bool ranges_ok = true;  // false when a step index does not fit the packed 16-bit range
     // lane-independent mode: list entry (k) and packed packet range of slot `lane`, and this ray's crossing list
     int ent0 = 0, rg0 = 0;
+    unsigned long long msk0 = 0ull;  // ... and which rays of the packet have a step in it (the backward's phase 1 examines only those)
     uint32_t head = kNullLink;
     int ncross = 0;
     if (FAST && fast) {
@@ -299,7 +300,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             int lo = 0x7fffffff, hi = -1;
             const bool some = hit && lane_step_range(tn, tf, tmin, tmax, dt, lo, hi);
             if (!some) lo = 0x7fffffff, hi = -1;
-            if (__ballot(some) != 0ull) {  // wave-uniform
+            const unsigned long long somem = __ballot(some);
+            if (somem != 0ull) {  // wave-uniform
                 if constexpr (HALF) {
                     // render path: no list is handed to a backward, so the packet's step range (two wave reductions per listed
                     // primitive) is not needed -- only the test that every step index fits the crossing table's field
@@ -316,6 +318,7 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                     if (lane == nh) {
                         ent0 = k;
                         rg0 = wlo | (whi << 16);
+                        msk0 = somem;
                     }
                 }
                 // the record moves to its list slot (nh <= c: nothing unread is overwritten; one wave, in-order LDS)
@@ -424,19 +427,24 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                 const size_t pk = (size_t)n * K + ent0;
                 const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
                 if (idx < (uint32_t)p.pl_cap) {
-                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)lane, (uint32_t)rg0);
+                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint4(((uint32_t)tidx << 9) | (uint32_t)lane, (uint32_t)rg0,
+                                                                        (uint32_t)msk0, (uint32_t)(msk0 >> 32));
                 } else {
                     raise_flag(flags, kFlagListOverflow);
                     flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;  // (region zeroed by the host)
                 }
             }
         } else {
+            // (the slot-synchronous layout has no room for a mask per list slot -- up to 512 of them: every active ray is a
+            //  candidate for every entry of such a packet, as it was for all packets before round 6)
+            const unsigned long long actm = __ballot(active);
             for (int j = lane; j < nh; j += kWave) {
                 const int k = s_b[j] & 0xffffff;
                 const size_t pk = (size_t)n * K + k;
                 const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
                 if (idx < (uint32_t)p.pl_cap) {
-                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint2(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j]);
+                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint4(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j],
+                                                                        (uint32_t)actm, (uint32_t)(actm >> 32));
                 } else {
                     raise_flag(flags, kFlagListOverflow);
                     flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;

@@ -132,6 +132,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int w = 0; w < 4; ++w) v += dpp_f(v, w);
     return (rl_f(v, 0) + rl_f(v, 16)) + (rl_f(v, 32) + rl_f(v, 48));
 }
+// Twelve sums over the wave at once (the backward's pose sums): the same row_shr / row_bcast scan as wave_min / wave_max with
+// v_add_f32 -- an inclusive prefix sum inside every row of 16 lanes, then the row totals carried over -- but with the twelve
+// chains INTERLEAVED, so that every DPP read is twelve instructions behind the write it depends on and needs no wait states:
+// 72 VALU instructions for twelve sums, where twelve wave_sum() calls cost 12 x 15 plus the moves around them (round 6: the
+// ISA census of bwd_prim_kernel showed 253 VALU instructions per wave in this reduction, 6 % of all the kernel executes).
+// Lane 63 ends up with the totals; all 64 lanes must be enabled.
+__device__ __forceinline__ void wave_sum12_lane63(float (&v)[12]) {
+#define MVP_ADD12(CTRL_)                                                                                  \
+    "v_add_f32_dpp %0, %0, %0 " CTRL_ "\n\tv_add_f32_dpp %1, %1, %1 " CTRL_ "\n\t"                        \
+    "v_add_f32_dpp %2, %2, %2 " CTRL_ "\n\tv_add_f32_dpp %3, %3, %3 " CTRL_ "\n\t"                        \
+    "v_add_f32_dpp %4, %4, %4 " CTRL_ "\n\tv_add_f32_dpp %5, %5, %5 " CTRL_ "\n\t"                        \
+    "v_add_f32_dpp %6, %6, %6 " CTRL_ "\n\tv_add_f32_dpp %7, %7, %7 " CTRL_ "\n\t"                        \
+    "v_add_f32_dpp %8, %8, %8 " CTRL_ "\n\tv_add_f32_dpp %9, %9, %9 " CTRL_ "\n\t"                        \
+    "v_add_f32_dpp %10, %10, %10 " CTRL_ "\n\tv_add_f32_dpp %11, %11, %11 " CTRL_ "\n\t"
+    asm("s_nop 1\n\t" MVP_ADD12("row_shr:1 row_mask:0xf bank_mask:0xf") MVP_ADD12("row_shr:2 row_mask:0xf bank_mask:0xf")
+        MVP_ADD12("row_shr:4 row_mask:0xf bank_mask:0xf") MVP_ADD12("row_shr:8 row_mask:0xf bank_mask:0xf")
+        MVP_ADD12("row_bcast:15 row_mask:0xa bank_mask:0xf") MVP_ADD12("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+          "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+#undef MVP_ADD12
+}
 // make a value the compiler cannot prove uniform live in an SGPR
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uni(float v) {

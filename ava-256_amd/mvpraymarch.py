@@ -41,7 +41,7 @@ def wanted_from_histogram(words):
     mvp_list_demand's 256 bins of width 8 (counts clamped to 2047) + the maximum.  When the maximum is more than twice the
     99.9th percentile (one image-filling primitive among thousands), the lists are sized for 2 x that percentile and
     the few primitives above it stay on the ray-centric kernel, which marches only their packets: sizing N*K lists for one
-    primitive would cost gigabytes (N*K*cap*8 bytes; C2: 2.6 MB per unit of capacity)."""
+    primitive would cost gigabytes (N*K*cap*16 bytes; C2: 5.2 MB per unit of capacity)."""
     hist, mx = words[:256], int(words[256])
     n = sum(hist)
     if n == 0:
@@ -59,15 +59,16 @@ def wanted_from_histogram(words):
 # under the GIL, and a lost update costs one call a stale capacity, never a wrong result (lists over capacity are marched by
 # the ray-centric kernel).
 _LIST_DEMAND = {}  # (device index, H, W, K) -> _ListDemand
-_LIST_BYTES_MIN = 64 << 20  # the lists of a call may take this much ...
-_LIST_BYTES_PER_PRIM = 2048  # ... or this much per primitive (a quarter of an 8^3 slab), whichever is more
+LIST_ENTRY_WORDS = 4        # uint32 words per list entry (include/mvp_abi.h: key, step range, 64-bit ray mask)
+_LIST_BYTES_MIN = 128 << 20  # the lists of a call may take this much ...
+_LIST_BYTES_PER_PRIM = 4096  # ... or this much per primitive (half an 8^3 slab = 256 entries), whichever is more
 
 
 def _budget_clamp(cap, N, K):
-    """The memory budget of the lists: max(64 MiB, 2 KiB per primitive), never below 32 entries."""
+    """The memory budget of the lists: max(128 MiB, 4 KiB per primitive), never below 32 entries."""
     if N is not None and N * K > 0:
         budget = max(_LIST_BYTES_MIN, _LIST_BYTES_PER_PRIM * N * K)
-        cap = max(32, min(cap, budget // (8 * N * K) // 8 * 8))
+        cap = max(32, min(cap, budget // (4 * LIST_ENTRY_WORDS * N * K) // 8 * 8))
     return cap
 
 
@@ -98,7 +99,7 @@ def primlist_capacity(H, W, K, device=None, N=None):
     demand (`note_list_demand`: read one call late and without a host synchronisation; outliers clipped, decaying --
     `_ListDemand.note`, `wanted_from_histogram`), kept while the new value is within [0.6, 1] of the one in use so that
     the allocation size does not flutter.  Multiple of 8 (the library reads lists 32 bytes at a time), at most 2048, and --
-    when N is given -- at most what a memory budget of max(64 MiB, 2 KiB per primitive) allows, never below 32: primitives
+    when N is given -- at most what a memory budget of max(128 MiB, 4 KiB per primitive) allows, never below 32: primitives
     over the capacity are handled by the ray-centric kernel, correctly and slowly."""
     packets = ((H + 7) // 8) * ((W + 7) // 8)
     cap = (int(min(max(32.0, 4 * 10.0 * packets / max(K, 1)), 2048)) + 7) // 8 * 8
@@ -141,7 +142,7 @@ def alloc_handoff(N, H, W, K, dev):
     pl_cap = primlist_capacity(H, W, K, dev, N)
     rayaux = torch.empty((N, H, W, 4), device=dev, dtype=torch.int32)
     pl_count = torch.empty((N * K + 3 + N * ((H + 7) // 8) * ((W + 7) // 8),), device=dev, dtype=torch.int32)
-    pl_list = torch.empty((N * K, pl_cap, 2), device=dev, dtype=torch.int32)
+    pl_list = torch.empty((N * K, pl_cap, LIST_ENTRY_WORDS), device=dev, dtype=torch.int32)
     return rayaux, pl_count, pl_list, pl_cap
 
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MVP_ABI_VERSION 15
+#define MVP_ABI_VERSION 17
 
 #define MVP_OK 0
 #define MVP_ERR_BADARG (-1)      /* null pointer / non-positive size / non-finite scalar            */
@@ -89,8 +89,10 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  *                   scratch of the BACKWARD (per 8x8 ray packet: bits(max |grad_rayrgba|), rewritten by every call).
  *                   The backward may be called several times over one forward (retain_graph): what it marks in
  *                   this buffer (counter bits 30-31, flag bits 2-3) it clears again at the start of the next call.
- *   primlist        [N*K, primlist_cap, 2] uint32: per primitive the (packet, list slot, step range) records;
- *                   primlist_cap must be a multiple of 4 (lists are read 32 bytes at a time)
+ *   primlist        [N*K, primlist_cap, 4] uint32 (ABI 17; 2 words per record before): per primitive one 16-byte record per ray packet
+ *                   that touches it -- {(packet << 9) | list slot, first | last << 16 lattice step of the packet in the box,
+ *                   low and high word of the mask of the packet's 64 rays that have a step there}; 16-byte aligned;
+ *                   primlist_cap must be a multiple of 4
  * diag may be NULL; otherwise MVP_DIAG_WORDS uint32 counters are ACCUMULATED into it. */
 int mvp_march_forward(int N, int H, int W, int K, const float *raypos, const float *raydir, float stepsize,
                       const float *tminmax, const float *nodeaabb, const float *primpos, const float *primrot,

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.mvp_abi_version() == _lib.ABI_VERSION == 17
     assert b"bad argument" in lib.mvp_error_string(-1)
     assert lib.mvp_error_string(0) == b"ok"
 
@@ -176,7 +176,7 @@ def test_list_capacity_policy_on_the_host():
     """Host logic of the forward->backward list capacity (ava-256_amd/mvpraymarch.py): the first call of a shape uses the
     heuristic, later calls 1.25 x the measured demand, always a multiple of 8 (the library reads lists 32 bytes at a time
     and rejects capacities that are not a multiple of 4), at least 32, at most 2048.  The demand is robust: one outlier
-    primitive does not size everybody's list, a spike decays, the capacity does not flutter, and N*K*cap*8 bytes stay
+    primitive does not size everybody's list, a spike decays, the capacity does not flutter, and N*K*cap*16 bytes stay
     inside a budget."""
     import importlib
     op = importlib.import_module("ava256_amd.mvpraymarch")
@@ -221,11 +221,12 @@ def test_list_capacity_policy_on_the_host():
         seen.append(op.primlist_capacity(512, 512, 4096, dev))
     assert seen[0] == c_spike and seen[-1] <= 48 and sorted(seen, reverse=True) == seen
     assert len(set(seen)) <= 12, sorted(set(seen))              # steps, not a new allocation size per call
-    # memory budget: at C2 (80 x 4096 primitives) the lists never pass max(64 MiB, 2 KiB per primitive) = 640 MiB
+    # memory budget (16-byte entries since round 6): at C2 (80 x 4096 primitives) the lists never pass
+    # max(128 MiB, 4 KiB per primitive) = 1280 MiB
     st.note(1500)
     capb = op.primlist_capacity(512, 512, 4096, dev, N=80)
-    assert capb == 256 and 80 * 4096 * capb * 8 <= 2048 * 80 * 4096
-    assert op.primlist_capacity(512, 512, 4096, dev, N=1) == 1880   # one image: 64 MiB allow it
+    assert op.LIST_ENTRY_WORDS == 4 and capb == 256 and 80 * 4096 * capb * 16 <= 4096 * 80 * 4096
+    assert op.primlist_capacity(512, 512, 4096, dev, N=1) == 1880   # one image: 128 MiB allow it
     op._LIST_DEMAND.pop(key, None)
 
 

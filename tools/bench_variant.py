@@ -11,6 +11,10 @@ sys.path.insert(0, ROOT)
 if __name__ == "__main__":
     lib = os.path.abspath(sys.argv[1])
     from ava256_amd import _lib
+    if os.environ.get("MVP_VARIANT_ABI"):
+        # an OLDER library of a compatible call surface (round 6: ABI 15 reads 8-byte list records out of the 16-byte ones
+        # the operators allocate -- the buffer is merely larger than it needs): timing A/B only
+        _lib.ABI_VERSION = int(os.environ["MVP_VARIANT_ABI"])
     _lib.use_library(lib)
     import bench
     print("# library:", lib, file=sys.stderr)
