@@ -316,8 +316,9 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     if constexpr (WARP) fw = uni(fw);
     // list entries per round: all the workgroup can look at (kEntriesPerRound), fewer when the packets' step ranges are long
     // (64 lanes x range x entries <= 2^kRoundBudgetLog2 keeps a round's sample count, hence its scale exponent c, small)
-    const uint32_t epr = min((uint32_t)kEntriesPerRound, max(1u, (1u << kRoundBudgetLog2) / (64u * maxlen)));
-    const bool multi = cnt > epr;  // more than one round: walk the entries in ascending key order (see the header)
+    // (both can change once: a round whose rounding noise would pass its share of the budget is cut -- see the round loop)
+    uint32_t epr = min((uint32_t)kEntriesPerRound, max(1u, (1u << kRoundBudgetLog2) / (64u * maxlen)));
+    bool multi = cnt > epr;  // more than one round: walk the entries in ascending key order (see the header)
     __syncthreads();  // s_red is reused below
     if (cnt == 0u || dead) {  // this launch doubles as the zero-fill of the gradient buffers
         if constexpr (WARP) {
@@ -345,9 +346,11 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 
     if (tid == 0) s_qn[2] = 0u;
-    if (multi) {
-        // rank of every entry among the list's keys ((packet << 9) | slot: one entry per packet, all different); the key
-        // stream is wave-uniform -> scalar loads, four entries (32 bytes; pl_cap is a multiple of 4) at a time
+    // rank of every entry among the list's keys ((packet << 9) | slot: one entry per packet, all different); the key stream is
+    // wave-uniform -> scalar loads, four entries (64 bytes; pl_cap is a multiple of 4) at a time
+    // (ONE call site.  Where a round is cut, below, the ranks are made by a plain loop; an outer "start over" loop around this
+    //  call was built too: 4 spilled VGPRs and 10 more spilled SGPRs for the loop-carried state of a restart)
+    auto rank_entries = [&]() {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: HIP's uint4 class has no
         typedef const __attribute__((address_space(4))) u32x4 *cu4;   //  constructor from another address space)
         const cu4 l4 = reinterpret_cast<cu4>(reinterpret_cast<uintptr_t>(list));   // one entry per 16-byte element
@@ -361,7 +364,8 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             }
             s_perm[rank] = (uint16_t)e;
         }
-    }
+    };
+    if (multi) rank_entries();
     bool wbad = false;      // some sample weight was outside the bound: the integer sums cannot be trusted
     bool drained = false;   // grad_template holds the flushed sums of earlier rounds / passes (workgroup-uniform)
     float s_rgb = 1.f, s_a = 1.f, s_w = 1.f;  // this round's scales (workgroup-uniform)
@@ -407,7 +411,6 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         __syncthreads();
     };
     bool pass_b = false;  // this iteration re-marches the round it has just marched, for the residuals (workgroup-uniform)
-    float noise_cube = 0.f;  // sum over the rounds so far of (samples of the round)^3 (workgroup-uniform; header)
     for (uint32_t ebase = 0; ebase < cnt;) {
         if (tid < kLenBuckets) s_bucket[tid] = 0u;
         if (tid == 0) s_qn[1] = 0u, s_gext[0] = 0u, s_gext[1] = 0x7fffffffu;
@@ -540,10 +543,34 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             if constexpr (WARP) s_w = uni(res_mul / fmaxf(Bw, 1.0e-30f));
         }
         if constexpr (!RESID) {
-            // (rare: header, ACCUMULATED ROUNDING) this round would take the sums' rounding noise past the budget: the
-            // two-pass instantiation owns the primitive and overwrites every output (workgroup-uniform exit)
-            if (!pass_b) noise_cube += (float)round_samples * (float)round_samples * (float)round_samples;
-            if (noise_cube > kNoiseBudget * (float)V && s_qn[2] == 0u && !bad_bound) {
+            // (rare: header, ACCUMULATED ROUNDING) The noise budget kNoiseBudget * V bounds the sum over rounds of n_r^3; every
+            // round may spend the share its entries have in the list.  A round over its share -- a box that is DEEP along its
+            // rays: a dozen packets, thousands of samples each round -- is not marched: the rounds are cut shorter (n_r is
+            // proportional to the entries taken, so e' = e * sqrt(share / n^3) entries fit) and this one starts again; the
+            // entries are then walked in key order like those of any multi-round primitive, so every round, scale and flushed
+            // float is still the same on every run.  (Round 6.  Before, such a primitive went to the two-pass instantiation:
+            // 102 of 327 680 in the C2 training scene, marched twice by a small grid BEHIND this kernel -- 0.3-0.7 ms of serial
+            // tail per backward)  Only a single entry over its share still does.
+            const float n3c = (float)round_samples * (float)round_samples * (float)round_samples * (float)cnt;
+            const float budget_e = kNoiseBudget * (float)V * (float)(eend - ebase);   // (n^3 > share  <=>  n^3 cnt > budget e)
+            if (n3c > budget_e && s_qn[2] == 0u && !bad_bound) {
+                if (eend - ebase > 1u) {  // (workgroup-uniform)
+                    epr = max(1u, min(eend - ebase - 1u, (uint32_t)((float)(eend - ebase) * __builtin_sqrtf(budget_e / n3c))));
+                    __syncthreads();  // (everybody has read this attempt's counters before the next one clears them)
+                    if (!multi) {  // (then this is the first round, ebase = 0: nothing marched, nothing flushed)
+                        multi = true;
+                        // (the same ranks as rank_entries(), written as the plainest loop there is: this path is taken by a
+                        //  handful of primitives per launch, and a second inlined copy of the blocked scalar-load form costs
+                        //  every primitive 12 spilled SGPRs)
+                        for (uint32_t e = tid; e < cnt; e += kPrimBlock) {
+                            const uint32_t key = list[e].x;
+                            uint32_t rank = 0u;
+                            for (uint32_t j = 0; j < cnt; ++j) rank += (__builtin_nontemporal_load(&list[j].x) < key) ? 1u : 0u;
+                            s_perm[rank] = (uint16_t)e;
+                        }
+                    }
+                    continue;
+                }
                 if (tid == 0) {
                     atomicOr(p.pl_count + pk, kCountPrecise);
                     raise_flag(tail, kFlagBwdPrecise);

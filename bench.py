@@ -72,6 +72,25 @@ def render_bytes(N, H, W, K, V=512, voxel_bytes=16):
     return 16 * N * H * W + N * K * (V * voxel_bytes + 60) + 24 * N * (2 * K - 1)
 
 
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo: SMT siblings counted once (SURVEY.md 8d asks for the physical count
+    next to the CPU timing); None when the file does not say."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(N, H, W, K, slab, budget_s=20.0, cams=1):
     """Time the fp32 CPU port (oracle/, OpenMP over rays) on a bounded sample of the same workload (`cams` cameras of it per
     pass)."""
@@ -79,8 +98,9 @@ def cpu_baseline(N, H, W, K, slab, budget_s=20.0, cams=1):
     from ava256_amd.scene import make_scene
     from oracle.mvp_oracle import Oracle
 
-    cores = os.cpu_count() or 1
     o = Oracle("f32")
+    threads = o.max_threads()                 # what the OpenMP loops of the port run on (OMP_NUM_THREADS or every logical CPU)
+    logical, physical = os.cpu_count() or 1, physical_cores()
     s = make_scene(cams, H, W, K, device="cpu", seed=1112, slab=slab)
     npv = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in s.items()}
 
@@ -99,9 +119,10 @@ def cpu_baseline(N, H, W, K, slab, budget_s=20.0, cams=1):
     for _ in range(reps - 1):
         tt += one_pass()
     rays = reps * cams * H * W
-    return {"value": rays / tt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d x (%d camera(s) %dx%d, K=%d: raydirs+aabb+fwd+bwd) in %.1f s, OpenMP over rays, fp32" % (
-                reps, cams, H, W, K, tt)}
+    return {"value": rays / tt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "omp_max_threads": threads, "logical_cpus": logical, "physical_cores": physical,
+            "sample": "%d x (%d camera(s) %dx%d, K=%d: raydirs+aabb+fwd+bwd) in %.1f s, OpenMP over rays (%d threads on %s "
+                      "physical cores / %d logical CPUs), fp32" % (reps, cams, H, W, K, tt, threads, physical or "?", logical)}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -171,6 +192,20 @@ def camera_shard(args, rank, world):
 # ---------------------------------------------------------------------------------------------------------------
 # the two GPU legs
 # ---------------------------------------------------------------------------------------------------------------
+def l1_matting_gradient(rgba, bg=60.0, shift=3):
+    """d loss / d rayrgba of an L1 image loss behind the matting of the decode tail (models/autoencoder.py:254-269: irgbrec =
+    rayrgb + (1 - rayalpha) * bg; ddp-train.py:408 / losses.py:12-14: mean |irgbrec - image|), against a target that is the
+    same image shifted by `shift` pixels: what a TRAINING iteration hands the march's backward -- sign-valued (+-c per colour
+    channel, exactly 0 where prediction and target agree: the flat background), an alpha channel that is a signed sum of those,
+    nothing like the Gaussian of the headline step."""
+    x = rgba.detach().clone().requires_grad_(True)       # [N,H,W,4]
+    pred = x[..., :3] + (1.0 - x[..., 3:4]) * bg
+    with torch.no_grad():
+        target = torch.roll(pred, shifts=(shift, shift), dims=(1, 2))
+    (pred - target).abs().mean().backward()
+    return x.grad.detach()
+
+
 def make_march_step_gpu(args, rank, world, dev):
     """The hot path through the operator API on `dev`.  Returns (step, info)."""
     import ava256_amd as ops
@@ -188,6 +223,13 @@ def make_march_step_gpu(args, rank, world, dev):
     torch.manual_seed(5 + rank)
     gout = torch.randn(n_local, H, W, 4, device=dev)
     volradius, stepsize = s["volradius"], s["stepsize"]
+    if getattr(args, "gout", "randn") == "l1_matting":   # the upstream gradient of a training iteration (see l1_matting_gradient)
+        import ava256_amd as ops_
+        with torch.no_grad():
+            rp_, rd_, tm_ = ops_.compute_raydirs(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"], volradius)
+            rgba0 = ops_.mvpraymarch(rp_, rd_, stepsize, tm_, (s["primpos"], s["primrot"], s["primscale"]), s["template"], None)
+        gout = l1_matting_gradient(rgba0)
+        del rp_, rd_, tm_, rgba0
 
     def step():
         for k in prim_names:
@@ -241,7 +283,20 @@ def make_march_step_gpu(args, rank, world, dev):
         finally:
             _hooks.set_diag_buffer(None)
 
-    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render,
+    def marks():  # what the last backward left to its other kernels: primitives on the two-pass / on the ray-centric kernel
+        from ava256_amd import _hooks
+        keep = _hooks.keep_raysat
+        _hooks.keep_raysat = True
+        try:
+            step()
+            torch.cuda.synchronize(dev)
+            c = _hooks.last_pl_count[: n_local * K]
+            return {"two_pass_primitives": int(((c >> 30) & 1).sum()), "ray_centric_primitives": int(((c >> 31) & 1).sum()),
+                    "primitives": n_local * K}
+        finally:
+            _hooks.keep_raysat, _hooks.last_raysat, _hooks.last_pl_count = keep, None, None
+
+    return step, {"n_local": n_local, "H": H, "W": W, "K": K, "slab": slab, "N": N, "render": render, "marks": marks,
                   "fused_step": fused_step, "hit_packets_fn": hit_packets, "render_half": render_half, "to_half": to_half}
 
 
@@ -265,26 +320,40 @@ def time_calls(fn, dev, reps=5, warm=2):
     return ev0.elapsed_time(ev1) / reps
 
 
-def roofline_of(kavg, n_local, H, W, K, slab):
-    """Both march kernels of one workload against the HBM peak: algorithmic bytes per launch / HIP-event launch time."""
+def recorded_traffic(key):
+    """Per-launch HBM bytes of the march kernels of one workload from the RECORDED counter passes (profiles/traffic.json,
+    tools/make_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes), with the commit they were measured at -- or (None, None)."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return doc.get(key), doc.get("_by_workload", {}).get(key, {}).get("measured_at_commit", doc.get("_measured_at_commit"))
+    except Exception:
+        return None, None
+
+
+def roofline_of(kavg, n_local, H, W, K, slab, traffic_key=None):
+    """Both march kernels of one workload against the HBM peak: algorithmic bytes per launch / HIP-event launch time; `traffic`
+    = the recorded PMC bytes of that workload (traffic_key), when a pass exists."""
     bf, bb = algorithmic_bytes(n_local, H, W, K, slab ** 3)
+    rec, at = recorded_traffic(traffic_key) if traffic_key else (None, None)
     out = {}
     for name, nbytes in (("march_forward", bf), ("march_backward", bb)):
         ms = kavg.get(name)
         if ms:
             ach = nbytes / (ms * 1e-3) / 1e9
+            tr = (rec or {}).get(name)
             out[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "traffic": None}
+                         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "traffic": tr,
+                         "traffic_ratio": (tr / nbytes) if tr else None, "traffic_measured_at_commit": at if tr else None}
     return out
 
 
-def march_leg(args, rank, world, dev, workload, alpha_gain, steps=10, warmup=3):
+def march_leg(args, rank, world, dev, workload, alpha_gain, steps=10, warmup=3, gout="randn", traffic_key=None):
     """One more march workload on this rank, timed like the headline (same step through the operator API, HIP events per
     launch): SURVEY.md 8(d)'s secondary runs -- C3 / C4 at their per-GPU batch, and the "trained-like" scene (opacity x 40:
     about half the rays saturate, early termination primaccum.h:63-79, mvpraymarch_subset_kernel.h:76-97)."""
     from ava256_amd import _hooks as mm
     a = argparse.Namespace(**vars(args))
-    a.workload, a.alpha_gain, a.cams, a.scaling = workload, alpha_gain, None, "weak"
+    a.workload, a.alpha_gain, a.cams, a.scaling, a.gout = workload, alpha_gain, None, "weak", gout
     step, info = make_march_step_gpu(a, rank, world, dev)
     for _ in range(warmup):
         step()
@@ -303,7 +372,13 @@ def march_leg(args, rank, world, dev, workload, alpha_gain, steps=10, warmup=3):
     res = {"workload": "%s: %d cams/GPU, %dx%d, K=%d, alpha_gain %g" % (workload, N, H, W, K, alpha_gain),
            "ms_per_step": ms, "rays_per_s": N * H * W / (ms * 1e-3), "steps": steps, "kernel_ms": kavg,
            "saturated_ray_fraction": float((out.detach()[..., 3] >= 1.0 - 1e-6).float().mean()),
-           "roofline": roofline_of(kavg, N, H, W, K, slab)}
+           "roofline": roofline_of(kavg, N, H, W, K, slab, traffic_key)}
+    if gout != "randn":
+        res["upstream_gradient"] = ("d(mean L1 of rgb + (1 - alpha) * bg against the image shifted by 3 pixels) / d rayrgba: "
+                                    "sign-valued, zero on the flat background -- bench.l1_matting_gradient")
+        res["backward_marks"] = info["marks"]()
+        res["kernel_ms_note"] = ("march_backward = the whole mvp_march_backward call: bound prologue + bwd_prim_kernel + the "
+                                 "two-pass kernel + the ray-centric kernel (HIP events around the call)")
     del step, info, out
     torch.cuda.empty_cache()
     return res
@@ -347,7 +422,8 @@ def collective_identity(dist, dev, world):
                     "repetitions, MAX over ranks; busbw = 2 (n-1)/n * bytes / t" % (numel, reps)}
 
 
-def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None, config=None, graph=False):
+def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_bg, ddp=None, config=None, graph=False,
+              bucket_mb=None):
     """Reference-shaped training iterations (ava-256_amd/trainloop.py) -> dict for the `train` object.  `config` =
     config.load_train_config(...) of one of the reference's YAML files: its batch size per GPU and hyper-parameters."""
     from ava256_amd import _hooks as mm
@@ -364,10 +440,11 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
                                encoder=CodeEncoderStandIn()).to(dev)
     nparams = sum(p.numel() for p in model.parameters())
     ddp = (world > 1) if ddp is None else ddp
+    kw = {} if bucket_mb is None else {"bucket_cap_mb": int(bucket_mb)}   # DDP bucket size (default: one flat 256 MB bucket)
     if config is not None:
-        tr = Trainer.from_config(model, config, ddp=ddp, device_ids=[local_rank] if ddp else None, graph=graph)
+        tr = Trainer.from_config(model, config, ddp=ddp, device_ids=[local_rank] if ddp else None, graph=graph, **kw)
     else:
-        tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None, graph=graph)
+        tr = Trainer(model, ddp=ddp, device_ids=[local_rank] if ddp else None, graph=graph, **kw)
     state = {}
 
     def step():
@@ -383,6 +460,7 @@ def train_leg(workload, steps, warmup, rank, local_rank, world, dev, dist, with_
     out = {"workload": "%s: %d frames/GPU, %dx%d, K=%d" % (workload, N, H, W, K), "iters_per_s": steps / elapsed,
            "ms_per_iter": 1e3 * elapsed / steps, "steps": steps, "frames_per_s": N * world * steps / elapsed,
            "allreduce_mb": nparams * 4e-6 if ddp else 0.0, "param_mb": nparams * 4e-6,
+           "ddp_bucket_cap_mb": (int(bucket_mb) if bucket_mb is not None else 256) if ddp else None,
            "kernel_ms": kernel_averages(events), "final_loss": float(state["loss"]),
            "launch": ("one hipGraph replay per iteration (Trainer(graph=True): %d of the %d timed iterations)"
                       % (min(tr.graph_replays, steps), steps)) if tr.graph else "eager (one launch per kernel)",
@@ -493,6 +571,9 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank renders its own scene; strong: ONE scene's cameras are sharded")
     ap.add_argument("--alpha-gain", type=float, default=1.0, help="1.0 = random-init opacity (nothing saturates)")
+    ap.add_argument("--gout", default="randn", choices=["randn", "l1_matting"],
+                    help="upstream gradient of the march step: Gaussian (the headline) or the gradient of an L1 matting loss against "
+                         "a shifted target (what a training iteration hands the backward; the `train_like` leg of the default line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train leg (profiling runs of the march kernels)")
     ap.add_argument("--no-render", action="store_true", help="skip the no-grad render timing (profiling runs: keeps the "
@@ -512,6 +593,10 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     ap.add_argument("--bg", default="auto", choices=["auto", "on", "off"],
                     help="--mode train: the background MLP (auto: on except at C2, whose 80-frame batch holds 2 x 54 GB of bf16 "
                          "activations with it)")
+    ap.add_argument("--bucket-mb", type=int, default=None,
+                    help="--mode train with N > 1: DDP bucket_cap_mb (default 256 = ONE flat bucket, all-reduced after the backward; "
+                         "25 / 64 overlap the all-reduce of early buckets with the rest of the backward -- ddp-train.py:312 uses "
+                         "torch's default 25).  The first multi-GPU record can answer which wins: run once per value")
     ap.add_argument("--mode", default="march", choices=["march", "train"],
                     help="march (default, the contract metric + a `train` object); train: only the training loop, as "
                          "the headline value (iterations/s)")
@@ -543,7 +628,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
             cfg = load_train_config(args.config, args.opts)
         t = train_leg(args.workload, args.steps, args.warmup, rank, local_rank, world, dev, dist,
                       with_bg=(args.workload != "C2") if args.bg == "auto" else (args.bg == "on"),
-                      ddp=(world > 1 or args.dist_smoke), config=cfg)
+                      ddp=(world > 1 or args.dist_smoke), config=cfg, bucket_mb=args.bucket_mb)
         if rank == 0:
             print(json.dumps({
                 "metric": "train iters/sec, raymarch training path with a stand-in decoder (NOT ava-256's conv stacks)",
@@ -584,9 +669,10 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
     # SURVEY.md 8(d)'s secondary march runs, this rank: the trained-like scene and the other single-GPU configurations
     legs = {}
     if gpu and not args.no_render and not args.no_workloads and args.workload == "C2":
-        legs["saturated"] = march_leg(args, rank, world, dev, "C2", 40.0)
-        legs["C3"] = march_leg(args, rank, world, dev, "C3", 1.0, steps=20)
-        legs["C4"] = march_leg(args, rank, world, dev, "C4", 1.0, steps=20)
+        legs["saturated"] = march_leg(args, rank, world, dev, "C2", 40.0, traffic_key="C2_saturated")
+        legs["train_like"] = march_leg(args, rank, world, dev, "C2", 1.0, gout="l1_matting", traffic_key="C2")
+        legs["C3"] = march_leg(args, rank, world, dev, "C3", 1.0, steps=20, traffic_key="C3")
+        legs["C4"] = march_leg(args, rank, world, dev, "C4", 1.0, steps=20, traffic_key="C4")
     ident = collective_identity(dist, dev, world) if (dist is not None and not args.no_collective_check) else None
 
     # rays of all ranks per step: every rank contributes its own shard (gathered, so that uneven strong-scaling
@@ -713,6 +799,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
                     "hit_packets_per_launch": hp}
         if legs:
             out["saturated"] = legs.pop("saturated")
+            out["train_like"] = legs.pop("train_like")
             out["workloads"] = legs
         if ident is not None:
             out["collectives"] = ident

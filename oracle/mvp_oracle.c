@@ -56,6 +56,14 @@ static inline real rmax(real a, real b) { return (real)fmax((double)a, (double)b
 
 int mvpo_sizeof_real(void) { return (int)sizeof(real); }
 
+/* Threads the OpenMP loops below run with (bench.py states it next to the CPU timing); 1 when built without OpenMP. */
+#ifdef _OPENMP
+#include <omp.h>
+int mvpo_max_threads(void) { return omp_get_max_threads(); }
+#else
+int mvpo_max_threads(void) { return 1; }
+#endif
+
 /* ------------------------------------------------------------------------------------------
  * Ray generation.  utils_kernel.cu:12-52 (forward only; the reference backward kernel writes
  * nothing, utils_kernel.cu:54-95, and extensions/utils/utils.py:44-46 returns None grads).

@@ -35,6 +35,10 @@ class Oracle:
         assert self.lib.mvpo_sizeof_real() == np.dtype(self.dtype).itemsize
         self._creal = ctypes.c_double if precision == "f64" else ctypes.c_float
 
+    def max_threads(self):
+        """omp_get_max_threads() of the library's OpenMP loops (what a timing of this port actually ran on)."""
+        return int(self.lib.mvpo_max_threads())
+
     # -- helpers ------------------------------------------------------------------------------
     def _a(self, x):
         return np.ascontiguousarray(np.asarray(x), dtype=self.dtype)

@@ -173,7 +173,7 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["march", "train"])
+@pytest.mark.parametrize("mode", ["march", "train", "train_bucket25"])
 def test_collectives_of_the_multi_gpu_path_run_through_rccl_on_one_gpu(mode):
     """No multi-GPU node is available to these tests, and RCCL refuses two ranks on one device -- but a ONE-rank group
     still takes every collective of the N > 1 path through RCCL: `bench.py --dist-smoke` initialises the "nccl" group with
@@ -185,8 +185,10 @@ def test_collectives_of_the_multi_gpu_path_run_through_rccl_on_one_gpu(mode):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dist-smoke", "--steps", "3", "--warmup", "1", "--workload", "C1",
            "--no-cpu-baseline", "--no-train", "--no-render"]
-    if mode == "train":
+    if mode.startswith("train"):
         cmd += ["--mode", "train"]
+    if mode == "train_bucket25":   # several DDP buckets instead of the one flat one (--bucket-mb, ddp-train.py:312's default)
+        cmd += ["--bucket-mb", "25"]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -197,6 +199,7 @@ def test_collectives_of_the_multi_gpu_path_run_through_rccl_on_one_gpu(mode):
         c = j["collectives"]
         assert c["world_size"] == 1 and c["backend"] == "nccl" and c["allreduce_sums_ok"] is True
         assert c["allreduce_bytes"] == 46_870_000 * 4 and c["allreduce_ms"] > 0 and c["ranks"][0]["pci"] is not None
-    if mode == "train":
+    if mode.startswith("train"):
         t = j["train"]
         assert t["allreduce_mb"] > 0 and t["final_loss"] == t["final_loss"]      # DDP was on; the loss is finite
+        assert t["ddp_bucket_cap_mb"] == (25 if mode == "train_bucket25" else 256)

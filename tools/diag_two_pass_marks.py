@@ -46,3 +46,13 @@ print("rays with g == 0: %.3f;  per-packet max/min(nonzero) ratio: median %.1f  
       % (float((m == 0).float().mean()), float(ratio.median()), float(ratio.quantile(0.9)), float(ratio.quantile(0.99)), float(ratio.max()),
          float((ratio > 256).float().mean())))
 print("global max |g| %.3g, median nonzero %.3g; per-channel max %s" % (float(m.max()), float(m[m > 0].median()), g.abs().amax((0, 1, 2)).tolist()))
+# (round 6) the marked primitives themselves: list lengths (ray packets per primitive) and where they sit in the dispatch order
+marked = ((c >> 30) & 1).bool()
+if bool(marked.any()):
+    lens = cnt[marked].float()
+    ks = torch.nonzero(marked).flatten() % K
+    print("two-pass primitives: list length min %d median %d max %d; all primitives: median %d p99 %d max %d; distinct k among the marked: %d"
+          % (int(lens.min()), int(lens.median()), int(lens.max()), int(cnt.float().median()), int(cnt.float().quantile(0.99)),
+             int(cnt.max()), int(ks.unique().numel())))
+    img = torch.nonzero(marked).flatten() // K
+    print("marked per image: min %d max %d" % (int(torch.bincount(img, minlength=N).min()), int(torch.bincount(img, minlength=N).max())))
