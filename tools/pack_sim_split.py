@@ -52,3 +52,21 @@ print(cfg, "rays/prim %.1f"%np.mean([len(l) for l in lens]), "len mean %.2f medi
 base=np.sum([c[0] for c in res["cur"]])
 for k,v in res.items():
     print("%-10s VALU/prim %8.0f (%.3f)  wave-steps %.2f chunks %.2f"%(k, np.mean([c[0] for c in v]), np.sum([c[0] for c in v])/base, np.mean([c[1] for c in v]), np.mean([c[2] for c in v])))
+# (round 6, second policy) split in TWO halves only the rays longer than T, at most `room` of them per primitive (the queue has
+# kQueueCap - 64 * entries free slots): what a cheap in-kernel form could do
+print("---- halves of rays longer than T (at most `room` splits per primitive)")
+for T in (5, 6, 7, 8, 9):
+    for room in (32, 64, 128, 10**6):
+        tot = 0.0
+        for L in lens:
+            Ls = np.sort(L)[::-1]
+            items = []
+            nsplit = 0
+            for l in Ls:
+                if l > T and nsplit < room:
+                    items += [int(np.ceil(l / 2)), int(l // 2)]
+                    nsplit += 1
+                else:
+                    items.append(int(l))
+            tot += cost(items)[0]
+        print("T=%d room=%-7s VALU ratio %.3f" % (T, room if room < 10**6 else "inf", tot / base))
