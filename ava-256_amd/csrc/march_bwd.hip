@@ -436,7 +436,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         bool live2[kEntriesPerWave];
         bool toolong = false;
         uint32_t mylen = 0u;
-        uint32_t gq_hi = 0u;  // bits of the largest max |grad_rayrgba| over the packets this wave examines rays of (wave-uniform)
+        uint32_t gq_hi = 0u;  // bits of the largest max |grad_rayrgba| over the packets this wave's records name (wave-uniform)
         uint32_t ncmp = 0u;   // rays named by this wave's entries (wave-uniform, <= kEntriesPerWave * 64)
         uint2 *s_cmp = s_q + wave * (kEntriesPerWave * 64);
         {
@@ -491,7 +491,8 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                     // byte offsets computed in 32 bits: "SGPR base + zero-extended VGPR offset" addressing
                     const f3 o = ld3(at_bytes<float>(raypos_n, r * 12u)), d = ld3(at_bytes<float>(raydir_n, r * 12u));
                     const float2 tt = *at_bytes<float2>(tminmax_n, r * 8u);
-                    const int incs = (int)*at_bytes<uint32_t>(aux_n, r * 16u + 8u);
+                    const uint4 ax = *at_bytes<uint4>(aux_n, r * 16u);  // {key of the saturating sample, -, first step, -}
+                    const int incs = (int)ax.z;
                     // the same formulas the forward used for the packet range [elo, ehi] (the union of these over lanes)
                     const f3 r0 = rot_rows(q, o - q.pos) * q.scale, rd = rot_rows(q, d) * q.scale;
                     const f3 ird = mk3(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
@@ -502,7 +503,13 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                     int l0, h0;
                     if (lane_step_range(tn, tf, tt.x, tt.y, dt, l0, h0)) {
                         slo = max(l0, max(elo, incs));
-                        shi = min(h0, ehi);
+                        // (round 6) ... and nothing behind the sample that saturated the ray was evaluated by the forward
+                        // (key = step << 9 | slot, subset_kernel.h:76-97): such steps are not queued at all -- on a trained-like
+                        // scene, where 40 % of the rays saturate in the front shell, a fifth of the (ray, primitive) pairs the
+                        // lists name lie entirely behind that point and used to ride through the walk as dead lanes.  An
+                        // unsaturated ray's key is 0xffffffff: no clip.
+                        const int sats = (int)(ax.x >> 9);
+                        shi = min(min(h0, ehi), slot <= (ax.x & 511u) ? sats : sats - 1);
                     }
                 }
                 if (slo <= shi) {
@@ -520,10 +527,14 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         if (__ballot(toolong) != 0ull && lane == 0) atomicOr(s_qn + 2, 1u);
         {  // exact number of samples this round can add, and the bound of its upstream gradients: LDS atomics by one lane
            // per wave (sample counts < 2^24: exact in float)
+            // (the bound is the maximum over EVERY packet the round's records name, whether its rays turn out live or not, and
+            //  whichever wave looks at it: single-round primitives walk their records in the order the forward appended them,
+            //  which differs from run to run -- a bound that depended on which wave found live rays would make the scale, hence
+            //  the bits of the slab gradient, depend on that order.  Found by test_full_batch_properties[C4] in round 6.)
             const float wl = wave_sum((float)mylen);
-            if (lane == 0 && wl > 0.f) {
-                atomicAdd(s_qn + 1, (uint32_t)wl);
-                atomicMax(s_gext, gq_hi);
+            if (lane == 0) {
+                if (wl > 0.f) atomicAdd(s_qn + 1, (uint32_t)wl);
+                if (gq_hi != 0u) atomicMax(s_gext, gq_hi);
             }
         }
         __syncthreads();

@@ -391,3 +391,26 @@ def test_degenerate_primitive_inputs(ops, oracle64, case, mode):
 
 GT_TOL_DEGENERATE = 1e-3     # grad_template: the standing 1e-3 of max |g| (finite elements)
 POSE_TOL_DEGENERATE = 3e-2   # pose gradients: the standing white-noise bound
+
+
+@pytest.mark.parametrize("again", [1.0, 40.0, 200.0])
+def test_slab_gradient_is_bit_reproducible_whatever_the_append_order(ops, again):
+    """The forward appends a primitive's list records in whatever order its packets finish -- another order on every run --, and
+    a single-round primitive walks them in that order.  Everything a round's fixed-point scale is made of (its exact sample
+    count, the bound over the packets its records NAME) must therefore be independent of which wave looks at which record.
+    Round 6 broke that for a day: the bound was taken over the packets of the waves that found live rays, which on a SATURATED
+    scene -- where whole records lie behind the rays' saturation points -- depends on the order.  Five renders, all bits equal,
+    at opacity x 1 (nothing saturates), x 40 and x 200."""
+    from ava256_amd.scene import make_scene
+    s = make_scene(3, 256, 256, 1024, device="cuda", seed=77, alpha_gain=again)
+    gout = torch.randn(3, 256, 256, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    ref = None
+    for _ in range(5):
+        rgba, _, _, t = _forward_with_handoff(ops, s)
+        rgba.backward(gout)
+        g = t["template"].grad
+        assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+        if ref is None:
+            ref = g.clone()
+        else:
+            assert torch.equal(ref, g)
