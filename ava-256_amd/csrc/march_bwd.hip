@@ -12,9 +12,11 @@ namespace mvp {
 //   LDS: [V] float4 template slab | [4][Vp] int32 fixed-point gradient (plain sampler: packed as [2][Vp] int64) |
 //        ray queue (kQueueCap x 8 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
 //   Work proceeds in rounds of 8 list entries (ray packets):
-//     phase 1 (lanes = the packet's rays): exact ray/box interval -> rays that really cross the box are
-//             COMPACTED into the LDS queue (ballot + popcount prefix inside the wave, one LDS integer atomic per
-//             wave for the queue tail).  On head-like scenes only ~40 % of a packet's rays cross a given box.
+//     phase 1 (lanes = the rays the round's list records NAME -- each record carries the forward's mask of the packet's rays
+//             that have a lattice step in this box, ~40 % of them on head-like scenes; a wave compacts the rays its records
+//             name and examines them 64 at a time, round 6): exact ray/box interval, clipped to the ray's first step and to
+//             the sample that saturated it -> the rays that really have samples here go into the LDS queue, sorted by
+//             their number of steps (LDS integer atomics for bucket tickets).
 //     phase 2 (lanes = queued rays, evenly split over the 4 waves): every lane walks ITS OWN lattice steps
 //             through the box (aligned by entry step), samples the LDS slab, scatters into the LDS gradient.
 // Per-sample math: primaccum.h:81-98 with the prefix replaced by the forward's record
@@ -55,8 +57,10 @@ namespace mvp {
 //     round, so after the rounds r a cell's sum carries noise of about 0.29 / 2^31 * sqrt(8 / V * sum_r n_r^3) times the
 //     bound.  Ordinary primitives (C2: ~1200 samples, V = 512) sit at 1e-7 of the bound; a box that fills the image
 //     (tens of thousands of samples over several full rounds) reaches 2e-4 -- per-mille errors of ITS OWN gradient when
-//     the values are far below the bound.  A primitive whose sum_r n_r^3 passes kNoiseBudget * V (noise 3e-6 of the
-//     bound, rms) is therefore handed to the two-pass instantiation BEFORE the round that would pass it is marched.
+//     the values are far below the bound.  The sum over rounds of n_r^3 is therefore held below kNoiseBudget * V (noise
+//     3e-6 of the bound, rms): every round may spend the share its entries have in the list, and a round over its share is
+//     CUT -- fewer entries per round from there on (round 6; before, such a primitive went to the two-pass instantiation,
+//     which only a single record over its share still does).
 // The sums are exact integers, so a round's result does not depend on the order its samples arrive in.  The forward
 // appends list entries in a different order on every run; a multi-round primitive therefore walks its entries in
 // ascending packet order (a rank sort of the keys at kernel start, indices in LDS), which makes the composition of every
