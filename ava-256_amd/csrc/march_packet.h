@@ -419,41 +419,6 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
     packet_sync();
 
     if (MVP_DEBUG_STAGE(p) == 2) nh = 0;
-    // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
-    if (!BWD && !HALF && p.pl_count != nullptr && nh > 0) {
-        uint32_t *flags = p.pl_count + (size_t)p.N * K;
-        if (FAST && fast) {
-            if (lane < nh) {
-                const size_t pk = (size_t)n * K + ent0;
-                const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
-                if (idx < (uint32_t)p.pl_cap) {
-                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint4(((uint32_t)tidx << 9) | (uint32_t)lane, (uint32_t)rg0,
-                                                                        (uint32_t)msk0, (uint32_t)(msk0 >> 32));
-                } else {
-                    raise_flag(flags, kFlagListOverflow);
-                    flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;  // (region zeroed by the host)
-                }
-            }
-        } else {
-            // (the slot-synchronous layout has no room for a mask per list slot -- up to 512 of them: every active ray is a
-            //  candidate for every entry of such a packet, as it was for all packets before round 6)
-            const unsigned long long actm = __ballot(active);
-            for (int j = lane; j < nh; j += kWave) {
-                const int k = s_b[j] & 0xffffff;
-                const size_t pk = (size_t)n * K + k;
-                const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
-                if (idx < (uint32_t)p.pl_cap) {
-                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint4(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j],
-                                                                        (uint32_t)actm, (uint32_t)(actm >> 32));
-                } else {
-                    raise_flag(flags, kFlagListOverflow);
-                    flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;
-                }
-            }
-            if (!ranges_ok && lane == 0) raise_flag(flags, kFlagGlobal);
-        }
-    }
-
     // ---------------- march ----------------
     rtmin = fmaxf(rtmin, tmin);  // subset_kernel.h:63-64
     rtmax = fminf(rtmax, tmax);
@@ -946,6 +911,65 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                     s = nx;
                 }
             }
+        }
+    }
+
+    // ---------------- grad mode: hand this packet's list to the primitive-centric backward ----------------
+    // BEHIND the sweep (round 6; by itself a measured zero, profiles/r06_fwd_append_after.txt): the sweep knows where every ray
+    // SATURATED, and nothing behind that sample was evaluated (primaccum.h:63-79, subset_kernel.h:76) -- on a trained-like scene
+    // the rays saturate in the front shell and about half of the (ray, primitive) pairs the exact test listed lie entirely behind
+    // that point.  In lane-independent mode every saturated ray clears its bit in the masks of the list slots whose FIRST sample
+    // of that ray comes after its saturation key (its crossing table is still in LDS; the record area, free now, holds the masks:
+    // one 64-bit LDS atomic per dead crossing, nothing at all in packets without a saturated ray), and a record whose mask is
+    // empty is not appended: the backward's phase 1 neither loads it nor examines its rays.  The entries themselves are where the
+    // exact test left them: (ent0, rg0, msk0) in registers, s_b / s_a (which the slot-synchronous sweep only reads) otherwise.
+    if (!BWD && !HALF && p.pl_count != nullptr && nh > 0) {
+        uint32_t *flags = p.pl_count + (size_t)p.N * K;
+        if (FAST && fast) {
+            const bool satd = satkey != kNoSat;
+            if (__ballot(satd) != 0ull) {  // (wave-uniform)
+                unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(s_rec);
+                packet_sync();
+                if (lane < nh) s_mask[lane] = msk0;
+                packet_sync();
+                if (satd) {
+                    for (int c = 0; c < ncross; ++c) {  // this ray's crossings, in list order
+                        const uint32_t e = s_tab[c * kWave + lane];
+                        const uint32_t slot = e & 63u;
+                        if ((((e >> 17) << 9) | slot) > satkey) atomicAnd(s_mask + slot, ~(1ull << lane));
+                    }
+                }
+                packet_sync();
+                if (lane < nh) msk0 = s_mask[lane];
+            }
+            if (lane < nh && msk0 != 0ull) {
+                const size_t pk = (size_t)n * K + ent0;
+                const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
+                if (idx < (uint32_t)p.pl_cap) {
+                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint4(((uint32_t)tidx << 9) | (uint32_t)lane, (uint32_t)rg0,
+                                                                        (uint32_t)msk0, (uint32_t)(msk0 >> 32));
+                } else {
+                    raise_flag(flags, kFlagListOverflow);
+                    flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;  // (region zeroed by the host)
+                }
+            }
+        } else {
+            // (the slot-synchronous layout has no room for a mask per list slot -- up to 512 of them: every active ray is a
+            //  candidate for every entry of such a packet, as it was for all packets before round 6)
+            const unsigned long long actm = __ballot(active);
+            for (int j = lane; j < nh; j += kWave) {
+                const int k = s_b[j] & 0xffffff;
+                const size_t pk = (size_t)n * K + k;
+                const uint32_t idx = atomicAdd(p.pl_count + pk, 1u);
+                if (idx < (uint32_t)p.pl_cap) {
+                    p.pl_list[pk * (size_t)p.pl_cap + idx] = make_uint4(((uint32_t)tidx << 9) | (uint32_t)j, (uint32_t)s_a[j],
+                                                                        (uint32_t)actm, (uint32_t)(actm >> 32));
+                } else {
+                    raise_flag(flags, kFlagListOverflow);
+                    flags[3 + (size_t)n * p.tiles_x * p.tiles_y + tidx] = kPacketFwdOverflow;
+                }
+            }
+            if (!ranges_ok && lane == 0) raise_flag(flags, kFlagGlobal);
         }
     }
 

@@ -61,10 +61,22 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     assert d2["slowpath_packets"] == d2["packets_hit"] == d1["packets_hit"], (d1, d2)
     assert torch.equal(rgba1, rgba2)
     assert torch.equal(sat1, sat2)
-    assert torch.equal(cnt1[: N * K], cnt2[: N * K])
+    # The per-primitive record counts: equal -- unless rays saturate.  The lane-independent sweep drops, after its sweep, the
+    # records all of whose rays saturated before reaching the primitive (round 6); the slot-synchronous sweep has no per-slot ray
+    # masks and keeps them.  Such records name no sample either way.
+    c1, c2 = cnt1[: N * K] & 0x3fffffff, cnt2[: N * K] & 0x3fffffff
+    assert bool((c1 <= c2).all())
+    if again == 1.0:
+        assert torch.equal(c1, c2)
     # ... and the backward over either hand-off: same samples; the slab gradient is an integer sum (order-free, so
-    # bit-identical although the two forwards append list entries in different orders), pose gradients are fp32 sums.
-    assert torch.equal(t1["template"].grad, t2["template"].grad)
+    # bit-identical although the two forwards append list entries in different orders) whenever both hand-offs name the same
+    # packets; where records were dropped, the round's bound is taken over fewer packets and the same sums are rounded on
+    # another grid (1e-5 of the largest gradient).  Pose gradients are fp32 sums.
+    if torch.equal(c1, c2):
+        assert torch.equal(t1["template"].grad, t2["template"].grad)
+    else:
+        dg = float((t1["template"].grad - t2["template"].grad).abs().max())
+        assert dg <= 1e-5 * float(t2["template"].grad.abs().max()), dg
     for k in ("primpos", "primrot", "primscale"):
         g1, g2 = t1[k].grad, t2[k].grad
         assert float((g1 - g2).abs().max()) <= 1e-4 * float(g2.abs().max()), k
