@@ -8,14 +8,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from ava256_amd import _hooks  # noqa: E402
-from ava256_amd.trainloop import (CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel, SlabDecoderStandIn, Trainer,  # noqa: E402
-                                  make_training_batch)
+from ava256_amd.trainloop import (BackgroundMLPStandIn, CodeEncoderStandIn, ColorCalStandIn, RaymarchTrainModel,  # noqa: E402
+                                  SlabDecoderStandIn, Trainer, make_training_batch)
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "C2"
+with_bg = len(sys.argv) > 2 and sys.argv[2] == "bg"     # (round 6) ... with the background MLP in the decode tail
 dev = torch.device("cuda:0")
 N, H, W, K, slab = bench.WORKLOADS[workload]
 batch, volradius = make_training_batch(N, H, W, K, dev, seed=1112, ncams=80, nident=4, target_decoder=SlabDecoderStandIn(K, slab, seed=9))
-model = RaymarchTrainModel(SlabDecoderStandIn(K, slab, seed=1), volradius, colorcal=ColorCalStandIn(80, 4), encoder=CodeEncoderStandIn()).to(dev)
+model = RaymarchTrainModel(SlabDecoderStandIn(K, slab, seed=1), volradius, colorcal=ColorCalStandIn(80, 4),
+                           bgmodel=BackgroundMLPStandIn(80, 4) if with_bg else None, encoder=CodeEncoderStandIn()).to(dev)
 tr = Trainer(model)
 _hooks.keep_raysat = True
 grads = {}
