@@ -59,6 +59,24 @@ def main():
     np.savez_compressed(os.path.join(HERE, "bgmlp_multitile.npz"), **out2)
     print("bgmlp_multitile.npz:", {k: v.shape for k, v in out2.items() if not k.startswith("grad/mlp")})
 
+    # Third fixture (round 6), SAME module again: ONE ragged image of 29 x 31 = 899 pixels = three full tiles of the fused
+    # kernels and a fourth with 131 valid rows -- the non-zero hidden biases of the first fixture's parameters apply.
+    m.zero_grad()
+    g3 = torch.Generator().manual_seed(7)
+    B, H, W = 1, 29, 31
+    camindex, idindex = torch.tensor([0]), torch.tensor([1])
+    samplecoords = torch.rand(B, H, W, 2, generator=g3) * 2 - 1
+    gout = torch.randn(B, 3, H, W, generator=g3)
+    bg = m(camindex, idindex, samplecoords)
+    (bg * gout).sum().backward()
+    out3 = dict(camindex=camindex.numpy(), idindex=idindex.numpy(), samplecoords=samplecoords.numpy(), gout=gout.numpy(),
+                bg=bg.detach().numpy())
+    for k, p in m.named_parameters():
+        if k not in ("mlp.4.weight", "mlp.8.weight"):
+            out3["grad/" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "bgmlp_ragged.npz"), **out3)
+    print("bgmlp_ragged.npz:", {k: v.shape for k, v in out3.items() if not k.startswith("grad/mlp")})
+
 
 if __name__ == "__main__":
     main()

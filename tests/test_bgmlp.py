@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden", "bgmlp.npz")
 # the same module (parameters of bgmlp.npz) on 2 x 64 x 64 pixels = 2 x 16 tiles of the fused kernels, the second image
 # with sample coordinates in [-2.5, 2.5]; tests/golden/gen_bgmlp.py
 GOLDEN_MULTITILE = os.path.join(ROOT, "tests", "golden", "bgmlp_multitile.npz")
+# ... and on ONE ragged image of 29 x 31 = 899 pixels: three full tiles and a fourth with 131 valid rows (round 6)
+GOLDEN_RAGGED = os.path.join(ROOT, "tests", "golden", "bgmlp_ragged.npz")
 
 
 class _Both:
@@ -58,7 +60,7 @@ def _cos(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
 
 
-@pytest.mark.parametrize("fixture", [GOLDEN, GOLDEN_MULTITILE])
+@pytest.mark.parametrize("fixture", [GOLDEN, GOLDEN_MULTITILE, GOLDEN_RAGGED])
 def test_standin_matches_the_reference_module_on_cpu(fixture):
     m, g = _load("cpu", fixture=fixture)
     bg, grads = _run(m, g, "cpu")
@@ -80,7 +82,7 @@ def test_standin_matches_the_reference_module_on_cpu(fixture):
 
 @pytest.mark.gpu
 def test_fused_kernels_match_the_reference_module():
-    """bf16 operands and stored activations: the output (mean 100, spread from the 25x scale) is held to 2 % of its
+    """bf16 operands and stored activations: the output (mean 100, spread from the 25x scale) is held to 1.2 % of its
     spread.  Gradients: bf16 rounding of a pre-activation near zero flips its LeakyReLU slope (1 <-> 0.2), so against
     the float32 reference ANY bf16 execution of this network sits near 10 % norm-wise in the early layers (eager
     autocast: cosine 0.993 / 12 %, these kernels: 0.996 / 9 %, gpurun_out/r02y); held to cosine >= 0.99 and 15 %, and
@@ -95,20 +97,49 @@ def test_fused_kernels_match_the_reference_module_over_many_tiles():
     _check_fused_against(GOLDEN_MULTITILE)
 
 
+@pytest.mark.gpu
+def test_fused_kernels_match_the_reference_module_on_a_ragged_image():
+    """The same bounds on the ragged fixture: 899 pixels = 3.5 tiles of the fused kernels, non-zero hidden biases."""
+    _check_fused_against(GOLDEN_RAGGED)
+
+
+def _record(fixture, rows):
+    """What the bf16 kernels measure against the reference's fp32 module, per tensor, kept per run (gpurun_out/bgmlp_parity.json
+    -> profiles/r0N_bgmlp_parity.json): the bounds below are 'worst measured + margin', and this is where 'measured' is."""
+    import json
+    path = os.path.join(ROOT, "gpurun_out", "bgmlp_parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        doc = json.load(open(path)) if os.path.exists(path) else {}
+        doc[os.path.basename(fixture)] = rows
+        json.dump(doc, open(path, "w"), indent=1)
+    except OSError:
+        pass
+
+
 def _check_fused_against(fixture):
     m, g = _load("cuda", fixture=fixture)
     bg, grads = _run(m, g, "cuda")
     spread = np.abs(g["bg"] - 100.0).max()
-    assert np.abs(bg - g["bg"]).max() <= 2e-2 * spread, (np.abs(bg - g["bg"]).max(), spread)
+    rows = {"output_max_abs_over_spread": float(np.abs(bg - g["bg"]).max() / spread)}
+    for k, v in grads.items():
+        if g.has("grad/" + k):
+            ref = g["grad/" + k].reshape(v.shape)
+            rows[k] = {"cosine": _cos(v, ref), "norm_wise": float(np.linalg.norm(v - ref) / np.linalg.norm(ref))}
+    _record(fixture, rows)
+    # Bounds = the worst value MEASURED on the MI355X for that fixture + margin (profiles/r06_bgmlp_parity.json, written by
+    # _record above: output 0.6 / 0.9 / 0.9 % of the spread; worst cosine / norm-wise error of a gradient 0.9930 / 13.0 % on the
+    # small fixture -- its smallest tensor, idmod.0.weight --, 0.9945 / 10.8 % over 32 tiles, 0.9968 / 8.0 % on the ragged image).
+    # What bf16 operands cost: a pre-activation rounded across zero flips its LeakyReLU slope; eager bf16 autocast of the same
+    # module sits at 0.993 / 12 %.
+    cmin, nmax = {GOLDEN: (0.992, 0.14), GOLDEN_MULTITILE: (0.9935, 0.12), GOLDEN_RAGGED: (0.9955, 0.095)}[fixture]
+    assert np.abs(bg - g["bg"]).max() <= 1.2e-2 * spread, (np.abs(bg - g["bg"]).max(), spread)
     for k, v in grads.items():
         if not g.has("grad/" + k):
             continue
         ref = g["grad/" + k].reshape(v.shape)
-        # what bf16 operands cost (a pre-activation rounded across zero flips its LeakyReLU slope): measured on the MI355X
-        # cos 0.996 / 9 % norm-wise in the first layers, 0.9930 / 13.0 % on the smallest tensor (idmod.0.weight, r04a / r04c);
-        # eager bf16 autocast: 0.993 / 12 %.  Bounds = the worst measured value + margin
-        assert _cos(v, ref) >= 0.992, (k, _cos(v, ref))
-        assert np.linalg.norm(v - ref) <= 0.14 * np.linalg.norm(ref), (k, np.linalg.norm(v - ref) / np.linalg.norm(ref))
+        assert _cos(v, ref) >= cmin, (k, _cos(v, ref))
+        assert np.linalg.norm(v - ref) <= nmax * np.linalg.norm(ref), (k, np.linalg.norm(v - ref) / np.linalg.norm(ref))
 
 
 @pytest.mark.gpu
