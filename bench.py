@@ -690,11 +690,18 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         # background MLP (fused MFMA kernels); C2 = the 80-frame render batch, background off and (C2_bg) on.
         train = {"note": "stand-in decoder (per-primitive slab parameters), NOT ava-256's conv stacks",
                  "C3": train_leg("C3", 16, 5, rank, local_rank, world, dev, dist, with_bg=True),
-                 "C2": train_leg("C2", 10, 5, rank, local_rank, world, dev, dist, with_bg=False)}
+                 "C2": train_leg("C2", 20, 5, rank, local_rank, world, dev, dist, with_bg=False)}
+        if world > 1:
+            # N > 1: the same C3 leg with DDP's default bucket size (25 MB: the all-reduce of early buckets overlaps the rest of the
+            # backward, ddp-train.py:312) next to the ONE flat 256 MB bucket of the rows above -- the first multi-GPU record says
+            # which wins on xGMI without anybody having to pass --bucket-mb
+            b25 = train_leg("C3", 16, 5, rank, local_rank, world, dev, dist, with_bg=True, bucket_mb=25)
+            train["C3"]["ddp_bucket_25mb"] = {k: b25[k] for k in ("iters_per_s", "ms_per_iter", "frames_per_s", "steps",
+                                                                   "ddp_bucket_cap_mb", "final_loss")}
         if world == 1:
             # single process: the same iterations as ONE hipGraph replay each (Trainer(graph=True)); the eager rows above keep
             # the per-kernel HIP-event averages, which a replay cannot record
-            for key, (st, wu, bg) in (("C3", (16, 7, True)), ("C2", (10, 7, False))):
+            for key, (st, wu, bg) in (("C3", (16, 7, True)), ("C2", (20, 7, False))):
                 try:
                     g = train_leg(key, st, wu, rank, local_rank, world, dev, dist, with_bg=bg, graph=True)
                     train[key]["graph"] = {k: g[k] for k in ("iters_per_s", "ms_per_iter", "frames_per_s", "steps", "launch",
@@ -708,7 +715,7 @@ def main(argv=None, backend="nccl", make_step=None, device=None):
         if dist is not None:
             dist.all_reduce(free, op=dist.ReduceOp.MIN)
         if float(free.item()) > 160 * (1 << 30):
-            train["C2_bg"] = train_leg("C2", 10, 3, rank, local_rank, world, dev, dist, with_bg=True)
+            train["C2_bg"] = train_leg("C2", 20, 3, rank, local_rank, world, dev, dist, with_bg=True)
 
     if rank == 0:
         rays_per_step = cams_total * H * W
