@@ -45,16 +45,23 @@ struct CamRay {
 __device__ __forceinline__ CamRay ray_from_camera(f3 campos, const float *__restrict__ R /*[3,3] rows*/, float fx,
                                                   float fy, float cx, float cy, float px, float py, float volradius) {
 #pragma clang fp contract(off)
+    // (round 6) Reciprocals are v_rcp_f32 / v_rsq_f32 (1 ulp) and every quotient a product with one: the IEEE division
+    // sequence is ~10 VALU instructions and this function had twelve of them -- raydirs_kernel, a streaming-store kernel, was
+    // bound by its VALU at 0.20 ms (3.3 TB/s).  The reference's own build divides approximately too (-use_fast_math,
+    // extensions/utils/setup.py); the ray tests hold 1e-6 / 2e-6 / 2e-5 on origin / direction / interval.  The march that makes
+    // its rays itself (mvp_march_forward_cams) runs this same function, so the two stay bit-identical.
     CamRay c;
-    c.o = mk3(campos.x / volradius, campos.y / volradius, campos.z / volradius);  // utils_kernel.cu:32
-    const float qx = (px - cx) / fx, qy = (py - cy) / fy;
+    const float ivr = __builtin_amdgcn_rcpf(volradius);
+    c.o = mk3(campos.x * ivr, campos.y * ivr, campos.z * ivr);  // utils_kernel.cu:32
+    const float qx = (px - cx) * __builtin_amdgcn_rcpf(fx), qy = (py - cy) * __builtin_amdgcn_rcpf(fy);
     f3 d = mk3(__builtin_fmaf(R[3], qy, R[0] * qx) + R[6], __builtin_fmaf(R[4], qy, R[1] * qx) + R[7],
                __builtin_fmaf(R[5], qy, R[2] * qx) + R[8]);
-    const float inv = 1.0f / sqrtf(__builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
+    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)));
     d = mk3(d.x * inv, d.y * inv, d.z * inv);
     c.d = d;
-    const f3 t1 = mk3((-1.f - c.o.x) / d.x, (-1.f - c.o.y) / d.y, (-1.f - c.o.z) / d.z);
-    const f3 t2 = mk3((1.f - c.o.x) / d.x, (1.f - c.o.y) / d.y, (1.f - c.o.z) / d.z);
+    const f3 id = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const f3 t1 = mk3((-1.f - c.o.x) * id.x, (-1.f - c.o.y) * id.y, (-1.f - c.o.z) * id.z);
+    const f3 t2 = mk3((1.f - c.o.x) * id.x, (1.f - c.o.y) * id.y, (1.f - c.o.z) * id.z);
     c.tmin = fmaxf(max3f(fminf(t1.x, t2.x), fminf(t1.y, t2.y), fminf(t1.z, t2.z)), 0.f);
     c.tmax = min3f(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y), fmaxf(t1.z, t2.z));
     return c;

@@ -43,8 +43,20 @@ __global__ __launch_bounds__(kRdBlock) void raydirs_kernel(int N, int H, int W, 
                 px = pc.x;
                 py = pc.y;
             }
-            const CamRay c = ray_from_camera(ld3(campos + n * 3), camrot + n * 9, focal[n * 2 + 0], focal[n * 2 + 1],
-                                             princpt[n * 2 + 0], princpt[n * 2 + 1], px, py, volradius);
+            CamRay c;
+            if ((HW & 63) == 0) {
+                // (kernel-uniform) an image is a whole number of waves: the 64 rays of a wave share their camera, whose 19 floats
+                // then come through scalar loads instead of 19 vector loads per ray
+                const int nu = __builtin_amdgcn_readfirstlane(n);
+                const float *cp = campos + nu * 3, *cr = camrot + nu * 9, *cf = focal + nu * 2, *cc = princpt + nu * 2;
+                const float Rm[9] = {cload(cr), cload(cr + 1), cload(cr + 2), cload(cr + 3), cload(cr + 4),
+                                     cload(cr + 5), cload(cr + 6), cload(cr + 7), cload(cr + 8)};
+                c = ray_from_camera(mk3(cload(cp), cload(cp + 1), cload(cp + 2)), Rm, cload(cf), cload(cf + 1), cload(cc),
+                                    cload(cc + 1), px, py, volradius);
+            } else {
+                c = ray_from_camera(ld3(campos + n * 3), camrot + n * 9, focal[n * 2 + 0], focal[n * 2 + 1],
+                                    princpt[n * 2 + 0], princpt[n * 2 + 1], px, py, volradius);
+            }
             o = c.o;
             d = c.d;
             reinterpret_cast<float2 *>(tminmax)[r] = make_float2(c.tmin, c.tmax);
