@@ -553,9 +553,12 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             const float Brgb = wrgb * Gq, Ba = fa * Gq, Bw = WARP ? fw * Gq : 1.f;
             bad_bound = gq_bits >= 0x7f800000u || !(Brgb < 1.0e30f) || !(Ba < 1.0e30f) || !(Brgb > 1.0e-30f) ||
                         !(Ba > 1.0e-30f) || !(Bw < 1.0e30f);
-            res_mul = kFixRange / (float)round_samples;
-            s_rgb = uni(res_mul / Brgb), s_a = uni(res_mul / Ba);
-            if constexpr (WARP) s_w = uni(res_mul / fmaxf(Bw, 1.0e-30f));
+            // (v_rcp_f32, 1 ulp: a scale need not be an exact quotient -- the sums are decoded with the reciprocal of the scale
+            //  that was applied, and kFixRange keeps 0.1 % of headroom; five IEEE divisions per wave and round were 1.2 % of
+            //  the kernel's instructions)
+            res_mul = kFixRange * fast_rcp((float)round_samples);
+            s_rgb = uni(res_mul * fast_rcp(Brgb)), s_a = uni(res_mul * fast_rcp(Ba));
+            if constexpr (WARP) s_w = uni(res_mul * fast_rcp(fmaxf(Bw, 1.0e-30f)));
         }
         if constexpr (!RESID) {
             // (rare: header, ACCUMULATED ROUNDING) The noise budget kNoiseBudget * V bounds the sum over rounds of n_r^3; every
@@ -974,7 +977,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             if (!pass_b && round_samples > 0u) {
                 // pass A's sums leave, and the SAME round is marched again -- phase 1 included, it is deterministic --
                 // accumulating the residuals pass A rounded away
-                flush_sums(1.0f / s_rgb, 1.0f / s_a, 1.0f / s_w);
+                flush_sums(fast_rcp(s_rgb), fast_rcp(s_a), fast_rcp(s_w));
                 pass_b = true;
                 continue;
             }
@@ -988,8 +991,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             return;
         }
         if (ebase + epr < cnt && round_samples > 0u) {  // more rounds follow
-            const float im = 1.0f / cur_mul;
-            flush_sums(im / s_rgb, im / s_a, im / s_w);
+            flush_sums(fast_rcp(s_rgb * cur_mul), fast_rcp(s_a * cur_mul), fast_rcp(s_w * cur_mul));
         }
         pass_b = false;
         ebase += epr;
@@ -1031,7 +1033,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         return;
     }
     {  // the slab gradient, written exactly once: sum / scale (of the last round's last pass)
-        const float i_rgb = 1.0f / (s_rgb * cur_mul), i_a = 1.0f / (s_a * cur_mul);
+        const float i_rgb = fast_rcp(s_rgb * cur_mul), i_a = fast_rcp(s_a * cur_mul);
         for (int v = tl; v < V; v += kPrimBlock) {
             const int z = v / sD, rem = v - z * sD;
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
@@ -1047,7 +1049,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         }
     }
     if constexpr (WARP) {  // grad_warp, written exactly once
-        const float i_w = 1.0f / (s_w * cur_mul);
+        const float i_w = fast_rcp(s_w * cur_mul);
         float *gW = p.grad_warp + pkl * (size_t)VW * 3;
         const int sDw = WH * WW;
         for (int v = tl; v < VW; v += kPrimBlock) {
