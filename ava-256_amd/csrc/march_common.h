@@ -582,6 +582,92 @@ __device__ __forceinline__ float4 tplate_lookup_general(const float *__restrict_
     }
     return v;
 }
+// ---- the same two lookups without branches (round 6; the forward's sampler in both sweeps, and the primitive-centric
+// backward's) ---------------------------------------------------------------------------------------------------------
+// tri_general + tri_inb guard every corner with its own bounds test: eight exec-mask regions per lookup, each with its own
+// load and its own wait (the use sits inside the region) -- eight dependent round trips per lookup where the plain sampler
+// has one.  Here every corner is READ: along each axis the two cells are clamped into the slab separately,
+//   ca = clamp(f, 0, T-1), cb = clamp(f + 1, 0, T-1)   (f = floor(i)),
+// and a corner that the reference's zero padding leaves out gets the WEIGHT zero instead (utils.h:459-498: a term that is
+// not added = a term times zero, for finite cells).  A corner outside the slab along one axis reads the cell of the corner
+// INSIDE along that axis (ca == cb there), so a non-finite cell poisons the sample only if the reference reads that cell
+// too; a sample with an axis entirely outside has no corner the reference reads and is forced to zero.  (What differs: a
+// +-Inf cell read through a zero weight gives NaN here where the reference's sum stays +-Inf -- both non-finite.)
+struct AxisZ {
+    float ca, cb;  // the two cells read along this axis (small integers held as floats)
+    float wa, wb;  // their weights: (x0 + 1) - i and i - x0 where the reference's corner is in bounds, else 0
+    bool live;     // some corner along this axis is in bounds
+};
+__device__ __forceinline__ AxisZ axis_zero_pad(float yn, float tm1 /* T - 1 */) {
+#pragma clang fp contract(off)
+    const float i = fmaxf(-100.f, fminf(100.f, (yn + 1.f) * 0.5f)) * tm1;  // utils.h:416-418
+    const float f = floorf(i);
+    AxisZ a;
+    a.ca = fminf(fmaxf(f, 0.f), tm1);
+    a.cb = fminf(fmaxf(f + 1.f, 0.f), tm1);
+    a.wa = (f >= 0.f && f <= tm1) ? (f + 1.f) - i : 0.f;
+    a.wb = (f >= -1.f && f < tm1) ? i - f : 0.f;
+    a.live = f >= -1.f && f <= tm1;
+    return a;
+}
+struct TriZ {
+    uint32_t c[8];           // cell indices of the corners 000, 001 (x + 1), 010 (y + 1), ..., 111: all inside the grid
+    v2f W00, W01, W10, W11;  // the natural weight pairs W_zy = (w_zy0, w_zy1), as in TriF
+    AxisZ ax, ay, az;
+    bool live;
+};
+__device__ __forceinline__ TriZ tri_zero_pad(f3 y, int D, int H, int W) {
+#pragma clang fp contract(off)
+    TriZ t;
+    t.ax = axis_zero_pad(y.x, (float)(W - 1)), t.ay = axis_zero_pad(y.y, (float)(H - 1)), t.az = axis_zero_pad(y.z, (float)(D - 1));
+    t.live = t.ax.live && t.ay.live && t.az.live;
+    // (z * H + y) * W + x in float: integers below 2^24 (the host checks the grid sizes), exact
+    const float fH = (float)H, fW = (float)W;
+    const float r00 = __builtin_fmaf(t.az.ca, fH, t.ay.ca), r01 = __builtin_fmaf(t.az.ca, fH, t.ay.cb);
+    const float r10 = __builtin_fmaf(t.az.cb, fH, t.ay.ca), r11 = __builtin_fmaf(t.az.cb, fH, t.ay.cb);
+    t.c[0] = (uint32_t)__builtin_fmaf(r00, fW, t.ax.ca), t.c[1] = (uint32_t)__builtin_fmaf(r00, fW, t.ax.cb);
+    t.c[2] = (uint32_t)__builtin_fmaf(r01, fW, t.ax.ca), t.c[3] = (uint32_t)__builtin_fmaf(r01, fW, t.ax.cb);
+    t.c[4] = (uint32_t)__builtin_fmaf(r10, fW, t.ax.ca), t.c[5] = (uint32_t)__builtin_fmaf(r10, fW, t.ax.cb);
+    t.c[6] = (uint32_t)__builtin_fmaf(r11, fW, t.ax.ca), t.c[7] = (uint32_t)__builtin_fmaf(r11, fW, t.ax.cb);
+    const v2f wxp{t.ax.wa, t.ax.wb}, wyp{t.ay.wa, t.ay.wb}, wzp{t.az.wa, t.az.wb};
+    const v2f wyzA = pk_mul_lo(wyp, wzp), wyzB = pk_mul_hi(wyp, wzp);  // (wyz00, wyz10), (wyz01, wyz11)
+    t.W00 = pk_mul_lo(wxp, wyzA), t.W01 = pk_mul_hi(wxp, wyzA);
+    t.W10 = pk_mul_lo(wxp, wyzB), t.W11 = pk_mul_hi(wxp, wyzB);
+    return t;
+}
+struct __attribute__((packed, aligned(4))) Node3 {  // one node of a warp grid: 12 bytes, ONE dwordx3 gather
+    float x, y, z;
+};
+// primsampler.h:48-63 with dowarp: fade from y, template sampled at y1 = warp(y) with zero padding, (r, g, b, alpha * fade).
+// y strictly inside (-1,1)^3: every corner of the warp lookup is in bounds (the general form then gives the clamped one).
+// Both forward sweeps call this one function (explicit fused operations: the same bits at both call sites).
+template <bool FADE8>
+__device__ __forceinline__ float4 sample_warped(const float *__restrict__ Wk, const float *__restrict__ Tk, f3 y, int WD,
+                                                int WH, int WW, int TD, int TH, int TW, float fadescale, float fadeexp) {
+#pragma clang fp contract(off)
+    const float fade = fade_pinned<FADE8>(y, fadescale, fadeexp);
+    const TriZ tw = tri_zero_pad(y, WD, WH, WW);
+    const Node3 *Wn = reinterpret_cast<const Node3 *>(Wk);
+    const Node3 n0 = Wn[tw.c[0]], n1 = Wn[tw.c[1]], n2 = Wn[tw.c[2]], n3 = Wn[tw.c[3]];
+    const Node3 n4 = Wn[tw.c[4]], n5 = Wn[tw.c[5]], n6 = Wn[tw.c[6]], n7 = Wn[tw.c[7]];
+    f3 y1;
+#define MVP_WSUM(M_)                                                                                              \
+    __builtin_fmaf(n7.M_, tw.W11.y, __builtin_fmaf(n6.M_, tw.W11.x, __builtin_fmaf(n5.M_, tw.W10.y,               \
+    __builtin_fmaf(n4.M_, tw.W10.x, __builtin_fmaf(n3.M_, tw.W01.y, __builtin_fmaf(n2.M_, tw.W01.x,               \
+    __builtin_fmaf(n1.M_, tw.W00.y, n0.M_ * tw.W00.x)))))))
+    y1.x = MVP_WSUM(x), y1.y = MVP_WSUM(y), y1.z = MVP_WSUM(z);
+#undef MVP_WSUM
+    const TriZ tt = tri_zero_pad(y1, TD, TH, TW);
+    const float4 *T4 = reinterpret_cast<const float4 *>(Tk);
+    const float4 c000 = T4[tt.c[0]], c001 = T4[tt.c[1]], c010 = T4[tt.c[2]], c011 = T4[tt.c[3]];
+    const float4 c100 = T4[tt.c[4]], c101 = T4[tt.c[5]], c110 = T4[tt.c[6]], c111 = T4[tt.c[7]];
+    TriF tf;
+    tf.off = 0u, tf.W00 = tt.W00, tf.W01 = tt.W01, tf.W10 = tt.W10, tf.W11 = tt.W11;
+    float4 v = tri_interp(tf, c000, c001, c010, c011, c100, c101, c110, c111);
+    if (!tt.live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    v.w = v.w * fade;
+    return v;
+}
 template <bool FADE8>
 __device__ __forceinline__ float fade_of(f3 y, float fadescale, float fadeexp) {
     if (FADE8) {

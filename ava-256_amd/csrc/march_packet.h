@@ -15,7 +15,7 @@ __device__ __forceinline__ void packet_sync() { __syncthreads(); }
 template <bool BWD, bool FADE8, bool WARP, int TS, bool HALF = false>
 __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, int *s_a, int *s_b, float4 *s_rec,
                                              uint32_t *s_tab, const bool emit_all) {
-    constexpr bool FAST = !BWD && !WARP;  // the lane-independent sweep exists for the plain forward only
+    constexpr bool FAST = !BWD;  // the lane-independent sweep exists for the forward only (round 6: the warp-field one too)
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt(lane);
 
@@ -511,7 +511,11 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                         if (s >= incs && strictly_inside(yp)) {
                             const f3 y = mk3(yp.xy.x, yp.xy.y, yp.z);
                             float4 v;
-                            if constexpr (HALF)
+                            if constexpr (WARP)
+                                v = sample_warped<FADE8>(p.warp + ((size_t)n * K + k) * ((size_t)p.WD * p.WH * p.WW * 3),
+                                                         T + (size_t)k * V4, y, p.WD, p.WH, p.WW, p.TD, p.TH, p.TW,
+                                                         p.fadescale, p.fadeexp);
+                            else if constexpr (HALF)
                                 v = sample_slab_h<FADE8, TS>(Th, (uint32_t)k * (uint32_t)(TS * TS * TS * 8), y, p.fadescale,
                                                              p.fadeexp);
                             else if constexpr (TS > 0)
@@ -605,9 +609,8 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
                                 float4 v;
                                 if (WARP) {  // primsampler.h:48-63 with dowarp: fade from y0, template sampled at warp(y0)
                                     const size_t VW3 = (size_t)p.WD * p.WH * p.WW * 3;
-                                    const f3 y1 = warp_lookup(p.warp + ((size_t)n * K + k) * VW3, y, p.WD, p.WH, p.WW);
-                                    v = tplate_lookup_general(T + (size_t)k * V4, y1, p.TD, p.TH, p.TW);
-                                    v.w *= fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                                    v = sample_warped<FADE8>(p.warp + ((size_t)n * K + k) * VW3, T + (size_t)k * V4, y, p.WD,
+                                                             p.WH, p.WW, p.TD, p.TH, p.TW, p.fadescale, p.fadeexp);
                                 } else {
                                     if constexpr (HALF)
                                         v = sample_slab_h<FADE8, TS>(Th, (uint32_t)k * (uint32_t)(TS * TS * TS * 8), y,
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(kWave) void march_kernel(const MarchParams p) {
     // slot-synchronous layout: 64 records + s_a + s_b; lane-independent layout: kFastSlots records + kFastCross rows
     constexpr int kSlowWords = kRecSlots * 16 + 2 * kMaxList;
     constexpr int kFastWords = kFastSlots * 16 + kFastCross * kWave;
-    constexpr int kWords = (!BWD && !WARP && kFastWords > kSlowWords) ? kFastWords : kSlowWords;
+    constexpr int kWords = (!BWD && kFastWords > kSlowWords) ? kFastWords : kSlowWords;
     __shared__ __attribute__((aligned(16))) uint32_t smem[kWords];
     float4 *s_rec = reinterpret_cast<float4 *>(smem);
     int *s_a = reinterpret_cast<int *>(smem + kRecSlots * 16);

@@ -16,7 +16,7 @@ zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
 warp = (torch.stack([xx, yy, zz], -1)[None, None] + 0.05 * torch.randn(N, K, 8, 8, 8, 3, device="cuda", generator=g)).contiguous()
 rp, rd, tm = ops.compute_raydirs(s["campos"], s["camrot"], s["focal"], s["princpt"], s["pixelcoords"], s["volradius"])
 out = {}
-for mode in ("prim", "ray"):
+for mode in ("plain", "prim", "ray"):   # "plain": the same scene through algo 0 (no warp field) -- what the warp field costs
     handoff = _hooks.patched_handoff(ray_centric=(mode == "ray"))
     t = {k: s[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
     w = warp.clone().requires_grad_(True)
@@ -28,7 +28,10 @@ for mode in ("prim", "ray"):
             v.grad = None
         ev[0].record()
         with handoff:
-            rgba = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], w, algo=1)
+            if mode == "plain":
+                rgba = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
+            else:
+                rgba = ops.mvpraymarch(rp, rd, s["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], w, algo=1)
         ev[1].record()
         rgba.backward(gout)
         ev[2].record()
@@ -36,5 +39,6 @@ for mode in ("prim", "ray"):
         if it > 0:
             fw += ev[0].elapsed_time(ev[1]) / 3
             bw += ev[1].elapsed_time(ev[2]) / 3
-    out[mode] = dict(fwd_ms=round(fw, 3), bwd_ms=round(bw, 3), gw_norm=float(w.grad.norm()), gt_norm=float(t["template"].grad.norm()))
+    out[mode] = dict(fwd_ms=round(fw, 3), bwd_ms=round(bw, 3), gw_norm=float(w.grad.norm()) if w.grad is not None else None,
+                     gt_norm=float(t["template"].grad.norm()))
 print(json.dumps(dict(N=N, H=H, W=W, K=K, **out)))
