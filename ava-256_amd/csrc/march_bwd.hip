@@ -176,7 +176,8 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     constexpr int kEntriesPerRound = prim_entries_per_round(PW), kQueueCap = prim_queue_cap(PW);
     const int TD = TS ? TS : p.TD, TH = TS ? TS : p.TH, TW = TS ? TS : p.TW;
     const int V = TD * TH * TW;
-    const int gH = TW, gD = TH * TW + kGradPadZ;  // gradient-array strides (words); x stride 1
+    constexpr int kPadZ = WARP ? 0 : kGradPadZ;  // (warp-field variant: cell indices shared with the slab, 8-byte cells)
+    const int gH = TW, gD = TH * TW + kPadZ;  // gradient-array strides (words); x stride 1
     const int Vp = TD * gD;
     float4 *s_T = smem4;
     // fixed-point sums: [4][Vp] int32, channel-planar (warp-field variant) -- or the same bytes as [2][Vp] int64, two channels
@@ -191,7 +192,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     // WARP: [warp grid as float4 (x,y,z,-)][3][VWp] fixed-point sums -- behind everything else (16-byte aligned: the
     // host sizes the part above as a multiple of 16 bytes)
     const int WD = WARP ? p.WD : 2, WH = WARP ? p.WH : 2, WW = WARP ? p.WW : 2;
-    const int VW = WD * WH * WW, gHw = WW, gDw = WH * WW + kGradPadZ, VWp = WD * gDw;
+    const int VW = WD * WH * WW, gDw = WH * WW + kPadZ, VWp = WD * gDw;
     float4 *s_W = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem4) + p.prim_lds_base);
     int *s_wacc = reinterpret_cast<int *>(s_W + VW);
 
@@ -345,6 +346,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     const uint32_t *aux_n = p.rayaux + img * 4;
     const int sW = 1, sH = TW, sD = TH * TW;  // voxel strides of the template slab
     const float mx = 0.5f * (float)(TW - 1), my = 0.5f * (float)(TH - 1), mz = 0.5f * (float)(TD - 1);
+    const float mwx = 0.5f * (float)(WW - 1), mwy = 0.5f * (float)(WH - 1), mwz = 0.5f * (float)(WD - 1);  // (warp grid)
     const float nfs_log2e = -p.fadescale * 1.44269504088896341f;  // exp(-fadescale * e) = exp2(nfs_log2e * e): one multiply
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c10 = 0.f, c11 = 0.f, c12 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
@@ -387,14 +389,14 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             const int gv = z * gD + rem;
             float4 g;
             int ia_, ib_, ic_, id_;
-            acc_read4<!WARP>(s_acc, Vp, gv, ia_, ib_, ic_, id_);
+            acc_read4<true>(s_acc, Vp, gv, ia_, ib_, ic_, id_);
             g.x = (float)ia_ * i_rgb, g.y = (float)ib_ * i_rgb, g.z = (float)ic_ * i_rgb, g.w = (float)id_ * i_a;
             if (drained) {
                 const float4 o_ = gd[v];
                 g.x += o_.x, g.y += o_.y, g.z += o_.z, g.w += o_.w;
             }
             gd[v] = g;
-            acc_clear4<!WARP>(s_acc, Vp, gv);
+            acc_clear4<true>(s_acc, Vp, gv);
         }
         if constexpr (WARP) {
             float *gWd = p.grad_warp + pkd * (size_t)VW * 3;
@@ -402,13 +404,12 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             for (int v = td; v < VW; v += kPrimBlock) {
                 const int z = v / sDw, rem = v - z * sDw;
                 const int gv = z * gDw + rem;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float g = (float)s_wacc[j * VWp + gv] * i_w;
-                    if (drained) g += gWd[v * 3 + j];
-                    gWd[v * 3 + j] = g;
-                    s_wacc[j * VWp + gv] = 0;
-                }
+                const long long w0 = reinterpret_cast<const long long *>(s_wacc)[gv];  // (x | y), like acc_read4
+                const int ix_ = (int)w0, iy_ = (int)((w0 - (long long)ix_) >> 32), iz_ = s_wacc[2 * VWp + gv];
+                float gx_ = (float)ix_ * i_w, gy_ = (float)iy_ * i_w, gz_ = (float)iz_ * i_w;
+                if (drained) gx_ += gWd[v * 3], gy_ += gWd[v * 3 + 1], gz_ += gWd[v * 3 + 2];
+                gWd[v * 3] = gx_, gWd[v * 3 + 1] = gy_, gWd[v * 3 + 2] = gz_;
+                reinterpret_cast<long long *>(s_wacc)[gv] = 0ll, s_wacc[2 * VWp + gv] = 0;
             }
         }
         drained = true;
@@ -708,40 +709,87 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                 if (__ballot(inside) == 0ull) continue;
                 if constexpr (WARP) {
                     // ---- warp-field sampler (primsampler.h:68-91 with dowarp; utils.h:504-643 twice) ----
+                    // Round 6: branch-free.  The first form guarded each of the 16 corners with its own bounds test (one exec
+                    // region, one LDS read and one wait each) and scattered 32 + 24 one-word atomics; here every corner is read --
+                    // a corner the zero padding leaves out has the weight 0 and reads a cell the sample reads anyway
+                    // (march_common.h: tri_zero_pad) --, the arithmetic runs on the register pairs of the plain sampler and the
+                    // sums are packed two per 64-bit atomic: (r | g), (b | a) per slab cell, (x | y) + z per warp node:
+                    // 16 + 16 LDS atomics per sample.
                     if (inside) {
-                        const float fade = fade_of<FADE8>(y, p.fadescale, p.fadeexp);
+                        float fade;
                         f3 ypow;
                         if (FADE8) {
                             const f3 y2 = y * y, y4 = y2 * y2;
+                            fade = fast_exp2(nfs_log2e * (y4.x * y4.x + y4.y * y4.y + y4.z * y4.z));
                             ypow = y4 * y2 * y;
                         } else {
+                            const f3 ay = mk3(fabsf(y.x), fabsf(y.y), fabsf(y.z));
+                            fade = fast_exp(-p.fadescale * (fast_pow(ay.x, p.fadeexp) + fast_pow(ay.y, p.fadeexp) +
+                                                            fast_pow(ay.z, p.fadeexp)));
                             const float e1 = p.fadeexp - 1.f;
-                            ypow = mk3(fast_pow(fabsf(y.x), e1) * (y.x > 0.f ? 1.f : -1.f),
-                                       fast_pow(fabsf(y.y), e1) * (y.y > 0.f ? 1.f : -1.f),
-                                       fast_pow(fabsf(y.z), e1) * (y.z > 0.f ? 1.f : -1.f));
+                            ypow = mk3(fast_pow(ay.x, e1) * (y.x > 0.f ? 1.f : -1.f),
+                                       fast_pow(ay.y, e1) * (y.y > 0.f ? 1.f : -1.f),
+                                       fast_pow(ay.z, e1) * (y.z > 0.f ? 1.f : -1.f));
                         }
-                        const TriG tw = tri_general(y, WD, WH, WW);  // y strictly inside: all 8 corners in bounds
-                        f3 y1 = mk3(0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            int vox;
-                            float w;
-                            if (tri_inb(tw, c, WD, WH, WW, vox, w)) {
-                                const float4 qw = s_W[vox];
-                                y1.x += qw.x * w, y1.y += qw.y * w, y1.z += qw.z * w;
-                            }
-                        }
-                        const TriG tt = tri_general(y1, TD, TH, TW);  // may leave the slab: zero padding
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            int vox;
-                            float w;
-                            if (tri_inb(tt, c, TD, TH, TW, vox, w)) {
-                                const float4 qv = s_T[vox];
-                                v.x += qv.x * w, v.y += qv.y * w, v.z += qv.z * w, v.w += qv.w * w;
-                            }
-                        }
+                        // (1) y1 = warp(y).  y is strictly inside: every corner of the warp grid is in bounds once the base corner
+                        //     is clamped (the plain sampler's form: one fma per index axis, float base corner, one conversion)
+                        const float iwx = fmaf(y.x, mwx, mwx), iwy = fmaf(y.y, mwy, mwy), iwz = fmaf(y.z, mwz, mwz);
+                        const float gx0 = fminf(floorf(iwx), (float)(WW - 2)), gy0 = fminf(floorf(iwy), (float)(WH - 2)),
+                                    gz0 = fminf(floorf(iwz), (float)(WD - 2));
+                        const float ux1 = iwx - gx0, uy1 = iwy - gy0, uz1 = iwz - gz0;
+                        const v2f uxp = {1.f - ux1, ux1}, uyp = {1.f - uy1, uy1}, uzp = {1.f - uz1, uz1};
+                        const int oH = WW, oD = WH * WW;
+                        const int wvb = (int)fmaf(gz0, (float)oD, fmaf(gy0, (float)oH, gx0));
+                        const v2f uyzA = pk_mul_lo(uyp, uzp), uyzB = pk_mul_hi(uyp, uzp);  // (uyz00, uyz10), (uyz01, uyz11)
+                        const v2f U00 = pk_mul_lo(uxp, uyzA), U01 = pk_mul_hi(uxp, uyzA);
+                        const v2f U10 = pk_mul_lo(uxp, uyzB), U11 = pk_mul_hi(uxp, uyzB);
+                        const float4 *Wp = s_W + wvb;
+#define MVP_LOADN(NAME_, IDX_)            \
+    const float4 NAME_##q = Wp[IDX_];     \
+    const v2f NAME_##l = {NAME_##q.x, NAME_##q.y};
+                        MVP_LOADN(n000, 0)
+                        MVP_LOADN(n001, 1)
+                        MVP_LOADN(n010, oH)
+                        MVP_LOADN(n011, oH + 1)
+                        MVP_LOADN(n100, oD)
+                        MVP_LOADN(n101, oD + 1)
+                        MVP_LOADN(n110, oD + oH)
+                        MVP_LOADN(n111, oD + oH + 1)
+#undef MVP_LOADN
+                        v2f y1l = pk_mul_lo(n000l, U00);
+                        y1l = pk_fma_hi(n001l, U00, y1l), y1l = pk_fma_lo(n010l, U01, y1l), y1l = pk_fma_hi(n011l, U01, y1l);
+                        y1l = pk_fma_lo(n100l, U10, y1l), y1l = pk_fma_hi(n101l, U10, y1l), y1l = pk_fma_lo(n110l, U11, y1l);
+                        y1l = pk_fma_hi(n111l, U11, y1l);
+                        float y1z = n000q.z * U00.x;
+                        y1z = fmaf(n001q.z, U00.y, y1z), y1z = fmaf(n010q.z, U01.x, y1z), y1z = fmaf(n011q.z, U01.y, y1z);
+                        y1z = fmaf(n100q.z, U10.x, y1z), y1z = fmaf(n101q.z, U10.y, y1z), y1z = fmaf(n110q.z, U11.x, y1z);
+                        y1z = fmaf(n111q.z, U11.y, y1z);
+                        // (2) the slab at y1 with the reference's zero padding (y1 may leave the slab)
+                        const TriZ tt = tri_zero_pad(mk3(y1l.x, y1l.y, y1z), TD, TH, TW);
+#define MVP_LOADC(NAME_, IDX_)              \
+    const float4 NAME_##q = s_T[IDX_];      \
+    const v2f NAME_##l = {NAME_##q.x, NAME_##q.y}, NAME_##h = {NAME_##q.z, NAME_##q.w};
+                        MVP_LOADC(c000, tt.c[0])
+                        MVP_LOADC(c001, tt.c[1])
+                        MVP_LOADC(c010, tt.c[2])
+                        MVP_LOADC(c011, tt.c[3])
+                        MVP_LOADC(c100, tt.c[4])
+                        MVP_LOADC(c101, tt.c[5])
+                        MVP_LOADC(c110, tt.c[6])
+                        MVP_LOADC(c111, tt.c[7])
+#undef MVP_LOADC
+                        v2f vl = pk_mul_lo(c000l, tt.W00), vh = pk_mul_lo(c000h, tt.W00);
+                        vl = pk_fma_hi(c001l, tt.W00, vl), vh = pk_fma_hi(c001h, tt.W00, vh);
+                        vl = pk_fma_lo(c010l, tt.W01, vl), vh = pk_fma_lo(c010h, tt.W01, vh);
+                        vl = pk_fma_hi(c011l, tt.W01, vl), vh = pk_fma_hi(c011h, tt.W01, vh);
+                        vl = pk_fma_lo(c100l, tt.W10, vl), vh = pk_fma_lo(c100h, tt.W10, vh);
+                        vl = pk_fma_hi(c101l, tt.W10, vl), vh = pk_fma_hi(c101h, tt.W10, vh);
+                        vl = pk_fma_lo(c110l, tt.W11, vl), vh = pk_fma_lo(c110h, tt.W11, vh);
+                        vl = pk_fma_hi(c111l, tt.W11, vl), vh = pk_fma_hi(c111h, tt.W11, vh);
+                        // (a sample whose y1 has an axis entirely outside the slab has eight zero weights and -- this kernel
+                        //  marches finite slabs only -- the value 0, like the reference's empty sum)
+                        float4 v;
+                        v.x = vl.x, v.y = vl.y, v.z = vh.x, v.w = vh.y;
                         const float alpha = v.w * fade;
                         const bool issat = key == satkey;
                         const float weight = issat ? (1.f - wbefore) : alpha * dt;
@@ -757,46 +805,107 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
                         const float gf = -(p.fadescale * p.fadeexp) * alpha * dLs.w;
                         f3 gy = ypow * gf;
                         dLs.w *= fade;
-#define MVP_FIXW(ACC_, IDX_, VAL_)                                                                  \
-    {                                                                                               \
-        const float x_ = (VAL_);                                                                    \
-        const int t_ = fix_rn(x_);                                                                  \
-        atomicAdd((ACC_) + (IDX_), (!RESID || !pass_b) ? t_ : fix_rn((x_ - (float)t_) * res_mul));  \
+                        const v2f dl = {dLs.x, dLs.y}, dh = {dLs.z, dLs.w};
+#define MVP_DOT4(NAME_, C_)                                 \
+    float NAME_;                                            \
+    {                                                       \
+        const v2f p_ = C_##l * dl + C_##h * dh;             \
+        NAME_ = p_.x + p_.y;                                \
     }
-                        f3 gi1 = mk3(0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            int vox;
-                            float w;
-                            if (tri_inb(tt, c, TD, TH, TW, vox, w)) {
-                                const float4 qv = s_T[vox];
-                                const int gv = (tt.z0 + (c >> 2)) * gD + (tt.y0 + ((c >> 1) & 1)) * gH + tt.x0 + (c & 1);
-                                MVP_FIXW(s_acc, gv, w * dLs.x * s_rgb)
-                                MVP_FIXW(s_acc, Vp + gv, w * dLs.y * s_rgb)
-                                MVP_FIXW(s_acc, 2 * Vp + gv, w * dLs.z * s_rgb)
-                                MVP_FIXW(s_acc, 3 * Vp + gv, w * dLs.w * s_a)
-                                tri_posgrad_acc(tt, c, qv.x * dLs.x + qv.y * dLs.y + qv.z * dLs.z + qv.w * dLs.w, gi1);
-                            }
+                        MVP_DOT4(d000, c000)
+                        MVP_DOT4(d001, c001)
+                        MVP_DOT4(d010, c010)
+                        MVP_DOT4(d011, c011)
+                        MVP_DOT4(d100, c100)
+                        MVP_DOT4(d101, c101)
+                        MVP_DOT4(d110, c110)
+                        MVP_DOT4(d111, c111)
+#undef MVP_DOT4
+                        const f3 gi1 = posgrad_zero_pad(tt, d000, d001, d010, d011, d100, d101, d110, d111);
+// two sums per 64-bit atomic: word = hi * 2^32 + lo (signed lo).  Pass B of a two-pass round adds what pass A rounded away.
+#define MVP_PACK2W(LO_, HI_) ((unsigned long long)(uint32_t)(LO_) | ((unsigned long long)(uint32_t)((HI_) + ((LO_) >> 31)) << 32))
+#define MVP_FIXP(PTR_, VLO_, VHI_)                                          \
+    {                                                                       \
+        const float xl_ = (VLO_), xh_ = (VHI_);                             \
+        int lo_ = fix_rn(xl_), hi_ = fix_rn(xh_);                           \
+        if (RESID && pass_b) {                                              \
+            lo_ = fix_rn((xl_ - (float)lo_) * res_mul);                     \
+            hi_ = fix_rn((xh_ - (float)hi_) * res_mul);                     \
+        }                                                                   \
+        atomicAdd((PTR_), MVP_PACK2W(lo_, hi_));                            \
+    }
+#define MVP_FIXS(PTR_, V_)                                                  \
+    {                                                                       \
+        const float x_ = (V_);                                              \
+        int t_ = fix_rn(x_);                                                \
+        if (RESID && pass_b) t_ = fix_rn((x_ - (float)t_) * res_mul);       \
+        atomicAdd((PTR_), t_);                                              \
+    }
+                        {  // utils.h:582-589: the slab's share, in fixed point
+                            const v2f qxy = {dLs.x * s_rgb, dLs.y * s_rgb}, qzw = {dLs.z * s_rgb, dLs.w * s_a};
+                            unsigned long long *Ap = reinterpret_cast<unsigned long long *>(s_acc);
+#define MVP_WSCATTER(CELL_, MUL_, WP_)                              \
+    {                                                               \
+        const v2f a_ = MUL_(qxy, WP_), b_ = MUL_(qzw, WP_);         \
+        MVP_FIXP(Ap + (CELL_), a_.x, a_.y)                          \
+        MVP_FIXP(Ap + Vp + (CELL_), b_.x, b_.y)                     \
+    }
+                            MVP_WSCATTER(tt.c[0], pk_mul_lo, tt.W00)
+                            MVP_WSCATTER(tt.c[1], pk_mul_hi, tt.W00)
+                            MVP_WSCATTER(tt.c[2], pk_mul_lo, tt.W01)
+                            MVP_WSCATTER(tt.c[3], pk_mul_hi, tt.W01)
+                            MVP_WSCATTER(tt.c[4], pk_mul_lo, tt.W10)
+                            MVP_WSCATTER(tt.c[5], pk_mul_hi, tt.W10)
+                            MVP_WSCATTER(tt.c[6], pk_mul_lo, tt.W11)
+                            MVP_WSCATTER(tt.c[7], pk_mul_hi, tt.W11)
+#undef MVP_WSCATTER
                         }
-                        const f3 g1 = mk3(mx * gi1.x, my * gi1.y, mz * gi1.z);  // dL/dy1
-                        f3 gi0 = mk3(0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            int vox;
-                            float w;
-                            if (tri_inb(tw, c, WD, WH, WW, vox, w)) {
-                                const float4 qw = s_W[vox];
-                                const int gv = (tw.z0 + (c >> 2)) * gDw + (tw.y0 + ((c >> 1) & 1)) * gHw + tw.x0 + (c & 1);
-                                MVP_FIXW(s_wacc, gv, w * g1.x * s_w)
-                                MVP_FIXW(s_wacc, VWp + gv, w * g1.y * s_w)
-                                MVP_FIXW(s_wacc, 2 * VWp + gv, w * g1.z * s_w)
-                                tri_posgrad_acc(tw, c, qw.x * g1.x + qw.y * g1.y + qw.z * g1.z, gi0);
-                            }
+                        // (3) dL/dy1, the warp grid's share of it, and dL/dy through the warp lookup
+                        const f3 g1 = mk3(mx * gi1.x, my * gi1.y, mz * gi1.z);
+                        {
+                            const v2f q1 = {g1.x * s_w, g1.y * s_w};
+                            const float q1z = g1.z * s_w;
+                            unsigned long long *Bp = reinterpret_cast<unsigned long long *>(s_wacc) + wvb;
+                            int *Zp = s_wacc + 2 * VWp + wvb;
+#define MVP_NSCATTER(OFF_, MUL_, WP_, WS_)                          \
+    {                                                               \
+        const v2f a_ = MUL_(q1, WP_);                               \
+        MVP_FIXP(Bp + (OFF_), a_.x, a_.y)                           \
+        MVP_FIXS(Zp + (OFF_), q1z * (WS_))                          \
+    }
+                            MVP_NSCATTER(0, pk_mul_lo, U00, U00.x)
+                            MVP_NSCATTER(1, pk_mul_hi, U00, U00.y)
+                            MVP_NSCATTER(oH, pk_mul_lo, U01, U01.x)
+                            MVP_NSCATTER(oH + 1, pk_mul_hi, U01, U01.y)
+                            MVP_NSCATTER(oD, pk_mul_lo, U10, U10.x)
+                            MVP_NSCATTER(oD + 1, pk_mul_hi, U10, U10.y)
+                            MVP_NSCATTER(oD + oH, pk_mul_lo, U11, U11.x)
+                            MVP_NSCATTER(oD + oH + 1, pk_mul_hi, U11, U11.y)
+#undef MVP_NSCATTER
                         }
-#undef MVP_FIXW
-                        gy.x += 0.5f * (float)(WW - 1) * gi0.x;
-                        gy.y += 0.5f * (float)(WH - 1) * gi0.y;
-                        gy.z += 0.5f * (float)(WD - 1) * gi0.z;
+#undef MVP_FIXS
+#undef MVP_FIXP
+#undef MVP_PACK2W
+                        {  // d(warp lookup)/d(index) for the node values dotted with dL/dy1: the plain sampler's tree
+#define MVP_DOT3(NAME_, N_) const float NAME_ = fmaf(N_##q.z, g1.z, fmaf(N_##q.y, g1.y, N_##q.x * g1.x));
+                            MVP_DOT3(e000, n000)
+                            MVP_DOT3(e001, n001)
+                            MVP_DOT3(e010, n010)
+                            MVP_DOT3(e011, n011)
+                            MVP_DOT3(e100, n100)
+                            MVP_DOT3(e101, n101)
+                            MVP_DOT3(e110, n110)
+                            MVP_DOT3(e111, n111)
+#undef MVP_DOT3
+                            const float dx00 = e001 - e000, dx10 = e011 - e010, dx01 = e101 - e100, dx11 = e111 - e110;
+                            const float gix = fmaf(uyzB.y, dx11, fmaf(uyzB.x, dx01, fmaf(uyzA.y, dx10, uyzA.x * dx00)));
+                            const float f00 = fmaf(ux1, dx00, e000), f10 = fmaf(ux1, dx10, e010);  // (y0,z0) (y1,z0)
+                            const float f01 = fmaf(ux1, dx01, e100), f11 = fmaf(ux1, dx11, e110);  // (y0,z1) (y1,z1)
+                            const float dy0 = f10 - f00, dy1 = f11 - f01;
+                            const float giy = fmaf(uz1, dy1, uzp.x * dy0);
+                            const float giz = fmaf(uy1, dy1, f01) - fmaf(uy1, dy0, f00);
+                            gy.x = fmaf(mwx, gix, gy.x), gy.y = fmaf(mwy, giy, gy.y), gy.z = fmaf(mwz, giz, gy.z);
+                        }
                         ra0 += gy.x, ra1 += gy.y, ra2 += gy.z;
                         rb0 = fmaf(t, gy.x, rb0), rb1 = fmaf(t, gy.y, rb1), rb2 = fmaf(t, gy.z, rb2);
                     }
@@ -1039,7 +1148,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
             const int gv = z * gD + rem;  // (y * TW + x) is the same in both layouts
             float4 g;
             int ia_, ib_, ic_, id_;
-            acc_read4<!WARP>(s_acc, Vp, gv, ia_, ib_, ic_, id_);
+            acc_read4<true>(s_acc, Vp, gv, ia_, ib_, ic_, id_);
             g.x = (float)ia_ * i_rgb, g.y = (float)ib_ * i_rgb, g.z = (float)ic_ * i_rgb, g.w = (float)id_ * i_a;
             if (drained) {  // (workgroup-uniform) earlier flushes sit in grad_template already; same owner thread
                 const float4 o_ = gT4l[v];
@@ -1055,12 +1164,11 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
         for (int v = tl; v < VW; v += kPrimBlock) {
             const int z = v / sDw, rem = v - z * sDw;
             const int gv = z * gDw + rem;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float g = (float)s_wacc[j * VWp + gv] * i_w;
-                if (drained) g += gW[v * 3 + j];
-                gW[v * 3 + j] = g;
-            }
+            const long long w0 = reinterpret_cast<const long long *>(s_wacc)[gv];  // (x | y), like acc_read4
+            const int ix_ = (int)w0, iy_ = (int)((w0 - (long long)ix_) >> 32), iz_ = s_wacc[2 * VWp + gv];
+            float gx_ = (float)ix_ * i_w, gy_ = (float)iy_ * i_w, gz_ = (float)iz_ * i_w;
+            if (drained) gx_ += gW[v * 3], gy_ += gW[v * 3 + 1], gz_ += gW[v * 3 + 2];
+            gW[v * 3] = gx_, gW[v * 3 + 1] = gy_, gW[v * 3 + 2] = gz_;
         }
     }
     if (tl < 12) {
@@ -1109,7 +1217,7 @@ __global__ __launch_bounds__(PW * 64, WARP ? 2 : kBwdOcc) void bwd_prim_kernel(c
 // at a time, so the kernel lasts as long as its largest primitive -- more waves on it, not more workgroups, shorten that.
 constexpr int kPreciseWaves = 4;
 template <bool FADE8, bool WARP>
-__global__ __launch_bounds__(kPreciseWaves * 64, 2) void bwd_prim_precise_kernel(const MarchParams p, const int total_blocks) {
+__global__ __launch_bounds__(kPreciseWaves * 64, WARP ? 1 : 2) void bwd_prim_precise_kernel(const MarchParams p, const int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     if ((p.pl_count[(size_t)p.N * p.K] & kFlagBwdPrecise) == 0u) return;
     // Which of this workgroup's blocks are marked: all its counters are looked at in ONE parallel sweep (the body's own test is a
@@ -1177,7 +1285,8 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     const size_t V = (size_t)TD * TH * TW;
     const bool norays = (long long)N * H * W == 0;
     if (!norays && (!raysat || !grad_rayrgba || !aligned16(grad_rayrgba))) return MVP_ERR_BADARG;
-    const size_t Vp = (size_t)TD * ((size_t)TH * TW + kGradPadZ);
+    const size_t padz = warp ? 0 : kGradPadZ;  // (bwd_prim_body: kPadZ)
+    const size_t Vp = (size_t)TD * ((size_t)TH * TW + padz);
     // float4 slab + [4][Vp] int32 + ray queue + reduce area (+ queue tail)
     // 2 or 3 waves per workgroup by the work a primitive has: ray packets per primitive (see the note at kEntriesPerWave)
     const int pw = ((long long)p.tiles_x * p.tiles_y * 4 > 5ll * K) ? 3 : 2;
@@ -1187,7 +1296,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
     if (warp) {  // + the warp grid (float4 per node) and its [3][VWp] accumulators
         lds = (lds + 15) & ~(size_t)15;
         p.prim_lds_base = (int)lds;
-        const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + kGradPadZ);
+        const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + padz);
         lds += VW * 16 + VWp * 12;
     }
 #ifdef MVP_DEBUG_HOOKS
@@ -1257,7 +1366,7 @@ extern "C" int mvp_march_backward(int N, int H, int W, int K, const float *raypo
             if (warp) {
                 lds2 = (lds2 + 15) & ~(size_t)15;
                 p2.prim_lds_base = (int)lds2;
-                const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + kGradPadZ);
+                const size_t VW = (size_t)WD * WH * WW, VWp = (size_t)WD * ((size_t)WH * WW + padz);
                 lds2 += VW * 16 + VWp * 12;
             }
             const dim3 g2((unsigned)(pb < 2048 ? pb : 2048)), b2(kPreciseWaves * 64);

@@ -596,6 +596,7 @@ __device__ __forceinline__ float4 tplate_lookup_general(const float *__restrict_
 struct AxisZ {
     float ca, cb;  // the two cells read along this axis (small integers held as floats)
     float wa, wb;  // their weights: (x0 + 1) - i and i - x0 where the reference's corner is in bounds, else 0
+    float sa, sb;  // d(wa)/di, d(wb)/di: -1 and +1 where the corner is in bounds, else 0 (backward only)
     bool live;     // some corner along this axis is in bounds
 };
 __device__ __forceinline__ AxisZ axis_zero_pad(float yn, float tm1 /* T - 1 */) {
@@ -605,14 +606,18 @@ __device__ __forceinline__ AxisZ axis_zero_pad(float yn, float tm1 /* T - 1 */) 
     AxisZ a;
     a.ca = fminf(fmaxf(f, 0.f), tm1);
     a.cb = fminf(fmaxf(f + 1.f, 0.f), tm1);
-    a.wa = (f >= 0.f && f <= tm1) ? (f + 1.f) - i : 0.f;
-    a.wb = (f >= -1.f && f < tm1) ? i - f : 0.f;
+    const bool ina = f >= 0.f && f <= tm1, inb = f >= -1.f && f < tm1;
+    a.wa = ina ? (f + 1.f) - i : 0.f;
+    a.wb = inb ? i - f : 0.f;
+    a.sa = ina ? -1.f : 0.f;
+    a.sb = inb ? 1.f : 0.f;
     a.live = f >= -1.f && f <= tm1;
     return a;
 }
 struct TriZ {
     uint32_t c[8];           // cell indices of the corners 000, 001 (x + 1), 010 (y + 1), ..., 111: all inside the grid
     v2f W00, W01, W10, W11;  // the natural weight pairs W_zy = (w_zy0, w_zy1), as in TriF
+    v2f wyzA, wyzB;          // (w_y0 w_z0, w_y1 w_z0), (w_y0 w_z1, w_y1 w_z1)
     AxisZ ax, ay, az;
     bool live;
 };
@@ -630,10 +635,28 @@ __device__ __forceinline__ TriZ tri_zero_pad(f3 y, int D, int H, int W) {
     t.c[4] = (uint32_t)__builtin_fmaf(r10, fW, t.ax.ca), t.c[5] = (uint32_t)__builtin_fmaf(r10, fW, t.ax.cb);
     t.c[6] = (uint32_t)__builtin_fmaf(r11, fW, t.ax.ca), t.c[7] = (uint32_t)__builtin_fmaf(r11, fW, t.ax.cb);
     const v2f wxp{t.ax.wa, t.ax.wb}, wyp{t.ay.wa, t.ay.wb}, wzp{t.az.wa, t.az.wb};
-    const v2f wyzA = pk_mul_lo(wyp, wzp), wyzB = pk_mul_hi(wyp, wzp);  // (wyz00, wyz10), (wyz01, wyz11)
-    t.W00 = pk_mul_lo(wxp, wyzA), t.W01 = pk_mul_hi(wxp, wyzA);
-    t.W10 = pk_mul_lo(wxp, wyzB), t.W11 = pk_mul_hi(wxp, wyzB);
+    t.wyzA = pk_mul_lo(wyp, wzp), t.wyzB = pk_mul_hi(wyp, wzp);  // (wyz00, wyz10), (wyz01, wyz11)
+    t.W00 = pk_mul_lo(wxp, t.wyzA), t.W01 = pk_mul_hi(wxp, t.wyzA);
+    t.W10 = pk_mul_lo(wxp, t.wyzB), t.W11 = pk_mul_hi(wxp, t.wyzB);
     return t;
+}
+// d(zero-padded trilinear form)/d(index position) for channel-dotted corner values d_zyx (utils.h:592-642: over the corners in
+// bounds, -+1 along the axis times the other two weights), as a tree: the four x edges give d/dx and the edge values, their y
+// combinations d/dy, the last one d/dz
+__device__ __forceinline__ f3 posgrad_zero_pad(const TriZ &t, float d000, float d001, float d010, float d011, float d100,
+                                               float d101, float d110, float d111) {
+    const float wxa = t.ax.wa, wxb = t.ax.wb, sxa = t.ax.sa, sxb = t.ax.sb;
+    const float e00 = fmaf(wxb, d001, wxa * d000), e01 = fmaf(wxb, d011, wxa * d010);  // (z0,y0) (z0,y1)
+    const float e10 = fmaf(wxb, d101, wxa * d100), e11 = fmaf(wxb, d111, wxa * d110);  // (z1,y0) (z1,y1)
+    const float s00 = fmaf(sxb, d001, sxa * d000), s01 = fmaf(sxb, d011, sxa * d010);
+    const float s10 = fmaf(sxb, d101, sxa * d100), s11 = fmaf(sxb, d111, sxa * d110);
+    f3 g;
+    g.x = fmaf(t.wyzB.y, s11, fmaf(t.wyzB.x, s10, fmaf(t.wyzA.y, s01, t.wyzA.x * s00)));
+    const float f0 = fmaf(t.ay.wb, e01, t.ay.wa * e00), f1 = fmaf(t.ay.wb, e11, t.ay.wa * e10);
+    const float t0 = fmaf(t.ay.sb, e01, t.ay.sa * e00), t1 = fmaf(t.ay.sb, e11, t.ay.sa * e10);
+    g.y = fmaf(t.az.wb, t1, t.az.wa * t0);
+    g.z = fmaf(t.az.sb, f1, t.az.sa * f0);
+    return g;
 }
 struct __attribute__((packed, aligned(4))) Node3 {  // one node of a warp grid: 12 bytes, ONE dwordx3 gather
     float x, y, z;

@@ -62,6 +62,9 @@ int march_common_checks(bool bwd, mvp::MarchParams &p) {
         return MVP_ERR_BADARG;
     if (p.K > 0 && (p.TD < 2 || p.TH < 2 || p.TW < 2)) return MVP_ERR_UNSUPPORTED;
     if (p.K >= (1 << 24)) return MVP_ERR_UNSUPPORTED;  // list entries pack k into 24 bits
+    // warp-field sampler: cell indices are formed in float (tri_zero_pad), exact below 2^24 cells per grid
+    if (p.warp && ((long long)p.TD * p.TH * p.TW >= (1ll << 24) || (long long)p.WD * p.WH * p.WW >= (1ll << 24)))
+        return MVP_ERR_UNSUPPORTED;
     if (p.campos) {
         if (bwd || p.raypos || p.raydir || p.tminmax) return MVP_ERR_BADARG;
         if (!p.camrot || !p.focal || !p.princpt) return MVP_ERR_BADARG;
