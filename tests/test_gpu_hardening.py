@@ -16,12 +16,15 @@ pytestmark = pytest.mark.gpu
 DBG_LIB = os.path.join(ROOT, "build_variants", "libmvp_dbg.so")
 
 
-def _forward_with_handoff(ops_mod, d):
+def _forward_with_handoff(ops_mod, d, warp=None):
     from ava256_amd import _hooks
     _hooks.keep_raysat = True
     rp, rd, tm = ops_mod.compute_raydirs(d["campos"], d["camrot"], d["focal"], d["princpt"], d["pixelcoords"], d["volradius"])
     t = {k: d[k].clone().requires_grad_(True) for k in ("primpos", "primrot", "primscale", "template")}
-    rgba = ops_mod.mvpraymarch(rp, rd, d["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"], None)
+    if warp is not None:
+        t["warp"] = warp.clone().requires_grad_(True)
+    rgba = ops_mod.mvpraymarch(rp, rd, d["stepsize"], tm, (t["primpos"], t["primrot"], t["primscale"]), t["template"],
+                               t.get("warp"), algo=1 if warp is not None else 0)
     sat, cnt = _hooks.last_raysat, _hooks.last_pl_count
     _hooks.keep_raysat = False
     _hooks.last_raysat = _hooks.last_pl_count = None
@@ -29,8 +32,9 @@ def _forward_with_handoff(ops_mod, d):
 
 
 @pytest.mark.skipif(not os.path.exists(DBG_LIB), reason="build_variants/libmvp_dbg.so not built (__graft_entry__.build())")
-@pytest.mark.parametrize("cfg", [(2, 128, 128, 512, 1.0), (1, 200, 168, 4096, 20.0), (1, 96, 96, 16384, 6.0), (1, 40, 40, 300, 8.0)],
-                         ids=lambda c: "N%d_%dx%d_K%d_a%g" % c)
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 512, 1.0), (1, 200, 168, 4096, 20.0), (1, 96, 96, 16384, 6.0), (1, 40, 40, 300, 8.0),
+                                 (2, 96, 104, 512, 1.0, (8, 8, 8), 0.05), (1, 72, 64, 300, 8.0, (5, 6, 7), 0.3)],
+                         ids=lambda c: "N%d_%dx%d_K%d_a%g" % c[:5] + ("_warp%dx%dx%d_n%g" % (c[5] + (c[6],)) if len(c) > 5 else ""))
 def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     """The forward has two march schedules: the lane-independent sweep (every ray walks its own samples) and the
     slot-synchronous one (the packet steps together; also the fallback beyond the fast path's limits).  Same sample
@@ -38,12 +42,18 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     The debug build of the library (-DMVP_DEBUG_HOOKS) forces the slot-synchronous sweep through the environment."""
     from ava256_amd import _hooks, _lib
     from ava256_amd.scene import make_scene
-    N, H, W, K, again = cfg
+    N, H, W, K, again = cfg[:5]
     s = make_scene(N, H, W, K, device="cuda", seed=5 + K, alpha_gain=again)
+    warp = None
+    if len(cfg) > 5:  # (round 6) the warp-field forward takes both sweeps too: one sampler (march_common.h: sample_warped)
+        (WD, WH, WW), noise = cfg[5], cfg[6]
+        zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, WD), torch.linspace(-1, 1, WH), torch.linspace(-1, 1, WW), indexing="ij")
+        warp = (torch.stack([xx, yy, zz], dim=-1)[None, None] +
+                noise * torch.randn(N, K, WD, WH, WW, 3, generator=torch.Generator().manual_seed(9))).contiguous().cuda()
     diag = torch.zeros(8, dtype=torch.int32, device="cuda")
     _hooks.set_diag_buffer(diag)
     gout = torch.randn(N, H, W, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
-    rgba1, sat1, cnt1, t1 = _forward_with_handoff(ops, s)
+    rgba1, sat1, cnt1, t1 = _forward_with_handoff(ops, s, warp)
     d1 = _hooks.read_diag()
     assert d1["packets_hit"] > 0 and d1["slowpath_packets"] < d1["packets_hit"], d1   # the fast sweep really ran
     rgba1.backward(gout)
@@ -51,7 +61,7 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     os.environ["MVP_DEBUG_SLOT_SWEEP"] = "1"
     _lib.use_library(DBG_LIB)
     try:
-        rgba2, sat2, cnt2, t2 = _forward_with_handoff(ops, s)
+        rgba2, sat2, cnt2, t2 = _forward_with_handoff(ops, s, warp)
         d2 = _hooks.read_diag()
         rgba2.backward(gout)
     finally:
@@ -74,6 +84,8 @@ def test_lane_independent_sweep_equals_slot_synchronous_sweep(ops, cfg):
     # another grid (1e-5 of the largest gradient).  Pose gradients are fp32 sums.
     if torch.equal(c1, c2):
         assert torch.equal(t1["template"].grad, t2["template"].grad)
+        if warp is not None:
+            assert torch.equal(t1["warp"].grad, t2["warp"].grad)
     else:
         dg = float((t1["template"].grad - t2["template"].grad).abs().max())
         assert dg <= 1e-5 * float(t2["template"].grad.abs().max()), dg
