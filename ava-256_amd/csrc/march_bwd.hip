@@ -9,8 +9,10 @@ namespace mvp {
 
 // =================================================================================================
 // Primitive-centric backward.  One workgroup (4 waves) per (image n, primitive k).
-//   LDS: [V] float4 template slab | [4][Vp] int32 fixed-point gradient (plain sampler: packed as [2][Vp] int64) |
-//        ray queue (kQueueCap x 8 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below).
+//   LDS: [V] float4 template slab | [2][Vp] int64 fixed-point gradient, two channels per word: (r | g), (b | a) |
+//        ray queue (kQueueCap x 8 B) | small reduce area.   Vp = padded voxel count (z stride TH*TW + kGradPadZ, see below;
+//        the warp-field variant has no pad: a cell index serves the slab read and its scatter) | warp-field variant only:
+//        [VW] float4 warp grid | [VW] int64 (x | y) + [VW] int32 z fixed-point sums of grad_warp.
 //   Work proceeds in rounds of 8 list entries (ray packets):
 //     phase 1 (lanes = the rays the round's list records NAME -- each record carries the forward's mask of the packet's rays
 //             that have a lattice step in this box, ~40 % of them on head-like scenes; a wave compacts the rays its records
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void packetmax_kernel(const float4 *__restrict
     }
 }
 
-// The four fixed-point sums of gradient cell gv.  PACKED (plain sampler): two 64-bit words, word = hi * 2^32 + lo with SIGNED
+// The four fixed-point sums of gradient cell gv.  PACKED (every instantiation since round 6): two 64-bit words, word = hi * 2^32 + lo with SIGNED
 // lo -- channels (r | g) in plane 0 and (b | a) in plane 1 -- so that a sample's scatter is 16 ds_add_u64 instead of 32
 // ds_add_u32: lo by sign extension, hi = (word - lo) >> 32, exact while |sum lo| < 2^31 (the per-round bound).
 template <bool PACKED>
@@ -166,7 +168,8 @@ __device__ __forceinline__ int fix_rn(float v) {
 // TS > 0: the slab is TS^3 (compile-time strides: the 32 atomics and 8 reads of a sample share ONE address register and
 // use immediate offsets); TS == 0: any slab size, strides in registers.
 // WARP: the warp-field sampler (algo 1, primsampler.h:53-58,82-88): a second LDS slab (the warp grid) and a second set of
-// fixed-point accumulators (grad_warp); the template is sampled at warp(y) with zero padding (general strides only).
+// fixed-point accumulators (grad_warp); the template is sampled at warp(y) with zero padding, evaluated without branches as
+// zero weights on cells the sample reads anyway (march_common.h: tri_zero_pad; general strides only).
 constexpr int kBwdOcc = 3;  // waves per SIMD the register allocation aims at (4 = at most 128 VGPRs: 20 spilled)
 // RESID: the two-pass instantiation (header, DYNAMIC RANGE): owns the primitives the plain one marked, nothing else.
 template <bool FADE8, int TS, int PW, bool WARP, bool RESID>
@@ -180,8 +183,7 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     const int gH = TW, gD = TH * TW + kPadZ;  // gradient-array strides (words); x stride 1
     const int Vp = TD * gD;
     float4 *s_T = smem4;
-    // fixed-point sums: [4][Vp] int32, channel-planar (warp-field variant) -- or the same bytes as [2][Vp] int64, two channels
-    // per word: (r | g), (b | a) (plain sampler: acc_read4 / the scatter of the walk)
+    // fixed-point sums: [2][Vp] int64, two channels per word: (r | g), (b | a) (acc_read4 / the scatter of the walk)
     int *s_acc = reinterpret_cast<int *>(smem4 + V);
     uint2 *s_q = reinterpret_cast<uint2 *>(s_acc + 4 * Vp);  // (Vp is even: 8-byte aligned)
     float *s_red = reinterpret_cast<float *>(s_q + kQueueCap);  // 64 floats
@@ -189,8 +191,8 @@ __device__ __forceinline__ void bwd_prim_body(const MarchParams &p, const int bl
     uint32_t *s_bucket = s_qn + 4;  // kLenBuckets words
     uint16_t *s_perm = reinterpret_cast<uint16_t *>(s_bucket + kLenBuckets);  // pl_cap entries: list index by rank
     uint32_t *s_gext = reinterpret_cast<uint32_t *>(s_red + 62);  // per round: bits(max), bits(min) of the queued rays' max |g|
-    // WARP: [warp grid as float4 (x,y,z,-)][3][VWp] fixed-point sums -- behind everything else (16-byte aligned: the
-    // host sizes the part above as a multiple of 16 bytes)
+    // WARP: [warp grid as float4 (x,y,z,-)] [VWp] int64 (x | y) sums, [VWp] int32 z sums -- behind everything else (16-byte
+    // aligned: the host sizes the part above as a multiple of 16 bytes)
     const int WD = WARP ? p.WD : 2, WH = WARP ? p.WH : 2, WW = WARP ? p.WW : 2;
     const int VW = WD * WH * WW, gDw = WH * WW + kPadZ, VWp = WD * gDw;
     float4 *s_W = reinterpret_cast<float4 *>(reinterpret_cast<char *>(smem4) + p.prim_lds_base);

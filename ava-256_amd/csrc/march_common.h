@@ -530,7 +530,9 @@ __device__ __forceinline__ float4 sample_slab_h(const void *__restrict__ Timg, u
 
 // ---- warp-field path (algo 1: PrimSamplerTW<true>, primsampler.h:53-58,82-88) -------------------------------------
 // The warped coordinate y1 may leave (-1,1)^3, so the template lookup needs the reference's general form: normalised
-// coordinate clamped to +-100, floor, zero padding through per-corner bounds tests (utils.h:414-498).
+// coordinate clamped to +-100, floor, zero padding through per-corner bounds tests (utils.h:414-498).  This guarded form is
+// what the ray-centric backward (march_packet.h) runs -- the always-correct owner, non-finite slabs included; the forward and
+// the primitive-centric backward use the branch-free form below.
 struct TriG {
     int x0, y0, z0;
     float wx0, wx1, wy0, wy1, wz0, wz1;
@@ -551,36 +553,6 @@ __device__ __forceinline__ bool tri_inb(const TriG &t, int c, int D, int H, int 
     w = ((c & 1) ? t.wx1 : t.wx0) * (((c >> 1) & 1) ? t.wy1 : t.wy0) * ((c >> 2) ? t.wz1 : t.wz0);
     vox = (z * H + y) * W + x;
     return x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < D;
-}
-// y1 = trilinear 3-channel lookup of the warp grid at y0 (y0 strictly inside: every corner is in bounds after the
-// base-corner clamp, same value as the zero-padded form)
-__device__ __forceinline__ f3 warp_lookup(const float *__restrict__ Wk, f3 y0, int D, int H, int W) {
-    TriG t = tri_general(y0, D, H, W);
-    f3 r = mk3(0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        int vox;
-        float w;
-        if (tri_inb(t, c, D, H, W, vox, w)) {
-            const float *q = Wk + (size_t)vox * 3;
-            r.x += q[0] * w, r.y += q[1] * w, r.z += q[2] * w;
-        }
-    }
-    return r;
-}
-__device__ __forceinline__ float4 tplate_lookup_general(const float *__restrict__ Tk, f3 y1, int D, int H, int W) {
-    TriG t = tri_general(y1, D, H, W);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        int vox;
-        float w;
-        if (tri_inb(t, c, D, H, W, vox, w)) {
-            const float4 q = *reinterpret_cast<const float4 *>(Tk + (size_t)vox * 4);
-            v.x += q.x * w, v.y += q.y * w, v.z += q.z * w, v.w += q.w * w;
-        }
-    }
-    return v;
 }
 // ---- the same two lookups without branches (round 6; the forward's sampler in both sweeps, and the primitive-centric
 // backward's) ---------------------------------------------------------------------------------------------------------
