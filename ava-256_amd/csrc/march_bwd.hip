@@ -165,11 +165,12 @@ __device__ __forceinline__ int fix_rn(float v) {
     return r;
 }
 
+// (WARP, round 6: the zero padding is evaluated without branches, as zero weights on cells the sample reads anyway --
+//  march_common.h: tri_zero_pad.)
 // TS > 0: the slab is TS^3 (compile-time strides: the 32 atomics and 8 reads of a sample share ONE address register and
 // use immediate offsets); TS == 0: any slab size, strides in registers.
 // WARP: the warp-field sampler (algo 1, primsampler.h:53-58,82-88): a second LDS slab (the warp grid) and a second set of
-// fixed-point accumulators (grad_warp); the template is sampled at warp(y) with zero padding, evaluated without branches as
-// zero weights on cells the sample reads anyway (march_common.h: tri_zero_pad; general strides only).
+// fixed-point accumulators (grad_warp); the template is sampled at warp(y) with zero padding (general strides only).
 constexpr int kBwdOcc = 3;  // waves per SIMD the register allocation aims at (4 = at most 128 VGPRs: 20 spilled)
 // RESID: the two-pass instantiation (header, DYNAMIC RANGE): owns the primitives the plain one marked, nothing else.
 template <bool FADE8, int TS, int PW, bool WARP, bool RESID>
