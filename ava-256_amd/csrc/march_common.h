@@ -728,7 +728,20 @@ __host__ __device__ inline bool packet_of_block(const MarchParams &p, int b, int
         if (n >= p.N) return false;
     }
     const int S = kStripRows * p.tiles_x;          // packet slots per strip
-    const int strip = (j / S) * F + band, jj = j % S;  // the strip of the image, the slot inside it
+    int m = j / S;                                  // this XCD's m-th strip of the image
+    if (F > 1) {
+        // XCDs that SHARE an image walk their strips in two interleaved runs -- 0, h, 1, h + 1, ... with h = half of the strips --
+        // instead of top-down: the top run gets heavier while the bottom run gets lighter (a head shot: background, head,
+        // background), so packets that only traverse and packets that sweep slabs are in flight together all the way instead
+        // of a light, a heavy and a light phase.  With 4 images on the chip the whole kernel is ~3 generations of packets and
+        // the phases do not average out (round 6: C3 forward 0.712 -> 0.684 ms, C4 0.950 -> 0.892; centre-out, i.e. heavy
+        // first, LOSES 7 % / 2 %).  Whole images (F = 1: tens of generations per XCD) keep the top-down order: the same
+        // permutation costs 1 % there, two runs of slabs competing for the 4 MB L2 (profiles/r06_fwd_strip_order.txt).
+        const int NS = (p.tiles_y + kStripRows - 1) / kStripRows, M = (NS + F - 1) / F, half = (M + 1) / 2;
+        if (m >= M) return false;
+        m = (m & 1) ? half + (m >> 1) : (m >> 1);
+    }
+    const int strip = m * F + band, jj = j % S;  // the strip of the image, the slot inside it
     const int row0 = strip * kStripRows;
     const int rows = p.tiles_y - row0 < kStripRows ? p.tiles_y - row0 : kStripRows;
     if (rows <= 0 || jj >= rows * p.tiles_x) return false;  // (a ragged last strip leaves some slots empty)
