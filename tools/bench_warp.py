@@ -7,6 +7,9 @@ import __graft_entry__  # noqa: F401
 import ava256_amd as ops
 from ava256_amd import _hooks
 from ava256_amd.scene import make_scene
+if os.environ.get("MVP_VARIANT_LIB"):   # timing A/B against a build_variants/ library (never the product path)
+    from ava256_amd import _lib
+    _lib.use_library(os.path.abspath(os.environ["MVP_VARIANT_LIB"]))
 
 N, H, W, K = [int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (4, 512, 512, 4096))]
 s = make_scene(N, H, W, K, device="cuda", seed=3, alpha_gain=1.0)
