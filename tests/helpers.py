@@ -55,10 +55,12 @@ class FragileRays:
     way); that matters with fade parameters that leave a visible opacity AT the box faces (fadescale well below 8) or
     very opaque slabs, and is nil for the reference's fade(8, 8) at ordinary opacities (e^-8 at the face)."""
 
-    def __init__(self, ref_sat, margin, gout, max_frac=None, min_allowed=2, edge=None, nsamples=None, label=None):
+    def __init__(self, ref_sat, margin, gout, max_frac=None, min_allowed=2, edge=None, nsamples=None, label=None,
+                 edge_jump=None):
         self.ref_sat, self.margin, self.gout = ref_sat, margin, gout
         self.max_frac, self.min_allowed = max_frac, min_allowed
-        self.edge_mask = None if edge is None else np.asarray(edge) > EDGE_JUMP
+        # `edge_jump`: a tighter threshold than EDGE_JUMP where the scene calls for one -- see edge_jump_for()
+        self.edge_mask = None if edge is None else np.asarray(edge) > (EDGE_JUMP if edge_jump is None else min(EDGE_JUMP, edge_jump))
         self.hits = None if nsamples is None else int((np.asarray(nsamples) > 0).sum())
         self.label = label or os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]   # (pytest names the running test)
         self.mask = None
@@ -91,6 +93,17 @@ class FragileRays:
         g = self.gout.copy()
         g[self.mask] = 0.0
         return g
+
+
+def edge_jump_for(fwd_tol_abs, template):
+    """The opacity increment at which ONE flipped inclusion decision moves a ray's colour by half the forward tolerance:
+    a flipped sample changes rgb by (increment x the sample's colour), so the threshold on the oracle's `edge` must follow
+    the ratio tolerance / largest slab colour.  EDGE_JUMP (5e-5) is that ratio for opaque scenes (max |rgba| ~ 255 x alpha);
+    a nearly transparent image of bright slabs has a tolerance 2e-4 x (a small max |rgba|) against the same colours --
+    fuzz seed 1847 (opacity x 0.5, fade(3.6, 2.6)): one ray, edge 4.96e-5, off by 0.0054 against 0.0052 while the oracle's
+    own fp32 build misses four other rays by 0.003 the same way.  Named by the float64 oracle, like every excused ray."""
+    cmax = float(np.abs(np.asarray(template)[..., :3]).max())
+    return 0.5 * float(fwd_tol_abs) / max(cmax, 1e-30)
 
 
 def scene_rays(oracle, s):
