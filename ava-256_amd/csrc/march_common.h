@@ -336,7 +336,7 @@ __device__ __forceinline__ AxisBounds axis_bounds(bool active, float o, float d,
         a.olo = uni(wave_min(active ? o : INFINITY));
         a.ohi = uni(wave_max(active ? o : -INFINITY));
     }
-    const float ird = 1.0f / d;
+    const float ird = fast_rcp(d);  // (1 ulp; the bounds only cull, with the slack of packet_hits_box, and the exact test follows)
     a.ilo = uni(wave_min(active ? ird : INFINITY));
     a.ihi = uni(wave_max(active ? ird : -INFINITY));
     const bool allpos = __ballot(active && !(d > 0.f)) == 0ull;

@@ -1013,7 +1013,9 @@ __device__ __forceinline__ void march_packet(const MarchParams &p, const int b, 
             float *sp = p.raysat + r * 3;
             MVP_STREAM_STOREF(sp, raysat.x), MVP_STREAM_STOREF(sp + 1, raysat.y), MVP_STREAM_STOREF(sp + 2, raysat.z);
         }
-        if (p.rayaux)
+        // (the backward reads a ray's record only through a list entry that names the ray: a packet that lists no primitive
+        //  -- more than half of them -- has no reader for its 16 bytes per ray)
+        if (p.rayaux && nh > 0)
             MVP_STREAM_STORE(reinterpret_cast<float4 *>(p.rayaux) + r,
                              make_float4(__uint_as_float(satkey), wbefore, __uint_as_float((uint32_t)incs), tend));
     }

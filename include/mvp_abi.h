@@ -82,8 +82,9 @@ int mvp_aabb_build(int N, int K, const float *primpos, const float *primrot, con
  * mvpraymarch.py:147-152); when given it is fully written (-1 where the ray never saturates).
  *
  * Grad-mode hand-off to the backward (all three may be NULL; then the backward uses its ray-centric path):
- *   rayaux          [N,H,W,4] uint32, fully written: {key of the saturating sample or 0xffffffff,
- *                   bits(alpha before it), first lattice step, bits(rtmax + 1e-5)}
+ *   rayaux          [N,H,W,4] uint32: {key of the saturating sample or 0xffffffff, bits(alpha before it), first lattice
+ *                   step, bits(rtmax + 1e-5)} -- written for the rays of every 8x8 packet that lists a primitive (the only
+ *                   ones the backward reads, through the list records that name them); other entries are left as they were
  *   primlist_count  [N*K + 3 + N*ceil(H/8)*ceil(W/8)] uint32; the first N*K + 3 words are zeroed HERE (on `stream`) then
  *                   filled: packets per primitive; a flags word; a reserved word; bits(max |raysat|).  The rest is
  *                   scratch of the BACKWARD (per 8x8 ray packet: bits(max |grad_rayrgba|), rewritten by every call).
