@@ -9,6 +9,9 @@ import test_gpu_parity as T
 from helpers import FragileRays, edge_jump_for
 from oracle.mvp_oracle import Oracle
 import ava256_amd as ops
+if os.environ.get("MVP_VARIANT_LIB"):   # a build_variants/ library instead of the product (diagnosis only)
+    from ava256_amd import _lib
+    _lib.use_library(os.path.abspath(os.environ["MVP_VARIANT_LIB"]))
 o64, o32 = Oracle("f64"), Oracle("f32")
 for seed in (int(x) for x in sys.argv[1:]):
     c = T.fuzz_draw(seed, o64)
