@@ -38,6 +38,8 @@ def load_krt_400940():
 SAT_BAND = 1e-4  # a ray may disagree with the float64 oracle on its saturating sample only inside this band
 HIT_FRAC = 1e-3  # ... on at most this fraction of the rays that hit anything (FragileRays.bound)
 MASK_RECORDS = []  # one entry per FragileRays use: written to gpurun_out/parity_masks.json at the end of a session (conftest.py)
+SAT_ROUNDOFF = 2e-6  # ... and a ray whose alpha passes 1 by less than THIS (fp32 round-off of a sum of ~10^2 increments) is fragile whether or
+#                      not its raysat shows it: at fine steps the neighbouring sample has the same colour to 1e-3 (fuzz seed 4093, see FragileRays)
 EDGE_JUMP = 5e-5  # ... and on including a sample that sits on a box face / the march bound (oracle `edge`, see FragileRays)
 
 
@@ -56,9 +58,10 @@ class FragileRays:
     very opaque slabs, and is nil for the reference's fade(8, 8) at ordinary opacities (e^-8 at the face)."""
 
     def __init__(self, ref_sat, margin, gout, max_frac=None, min_allowed=2, edge=None, nsamples=None, label=None,
-                 edge_jump=None):
+                 edge_jump=None, sat_roundoff=None):
         self.ref_sat, self.margin, self.gout = ref_sat, margin, gout
         self.max_frac, self.min_allowed = max_frac, min_allowed
+        self.sat_roundoff = sat_roundoff  # (the fuzz passes SAT_ROUNDOFF: see __call__)
         # `edge_jump`: a tighter threshold than EDGE_JUMP where the scene calls for one -- see edge_jump_for()
         self.edge_mask = None if edge is None else np.asarray(edge) > (EDGE_JUMP if edge_jump is None else min(EDGE_JUMP, edge_jump))
         self.hits = None if nsamples is None else int((np.asarray(nsamples) > 0).sum())
@@ -78,6 +81,13 @@ class FragileRays:
         diff = np.abs(hip_raysat - self.ref_sat).max(-1) > 1e-3 * max(1.0, np.abs(self.ref_sat).max())
         if self.edge_mask is not None:  # a ray that included one more / one fewer sample may also saturate elsewhere
             diff = diff & ~self.edge_mask
+        # The comparison above SEES a ray that saturated at another sample only when that sample's colour differs.  With fine
+        # steps it does not (dt = 1/512: neighbouring samples agree to 1e-3), yet the alpha gradient of the two samples swaps
+        # roles: fuzz seed 4093 (K = 1, 147 samples per ray) -- ONE ray whose alpha passes 1.0 by 3.2e-7 in float64 carries the
+        # whole 1.6e-3 error of the slab gradient, identically in every backward owner (tools/diag_pose_localize.py 4093
+        # template).  A margin inside fp32 round-off of the alpha sum is fragile by the oracle's own account.
+        if self.sat_roundoff is not None:
+            diff = diff | (np.asarray(self.margin) < self.sat_roundoff)
         unjustified = diff & ~(self.margin < SAT_BAND)
         assert unjustified.sum() == 0, ("rays saturate differently from the oracle outside the %g band" % SAT_BAND,
                                         int(unjustified.sum()), float(self.margin[unjustified].min()))

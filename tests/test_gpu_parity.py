@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from helpers import FragileRays, cosine, edge_jump_for, load_krt_400940, npf, scene_rays, to_dev
+from helpers import SAT_ROUNDOFF, FragileRays, cosine, edge_jump_for, load_krt_400940, npf, scene_rays, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -252,7 +252,7 @@ def test_randomized_configurations(ops, oracle64, oracle32, seed):
     if st["rays_hit"] == 0 or st["list_overflow"] > 0:
         pytest.skip("degenerate draw")
     fragile = FragileRays(ref_sat, st["margin"], gout, nsamples=st["nsamples"], max_frac=0.01, min_allowed=3, edge=st["edge"],
-                          edge_jump=edge_jump_for(FWD_TOL * max(1.0, np.abs(ref_rgba).max()), a[7]))
+                          edge_jump=edge_jump_for(FWD_TOL * max(1.0, np.abs(ref_rgba).max()), a[7]), sat_roundoff=SAT_ROUNDOFF)
     rgba, grads, diag = _march(ops, *a, fadescale, fadeexp, grad_out=fragile, mode=mode, warp=warp)
     fr = fragile.mask
     g2 = fragile.masked()

@@ -12,6 +12,8 @@ from oracle.mvp_oracle import Oracle
 import ava256_amd as ops
 o64 = Oracle("f64")
 seed = int(sys.argv[1])
+WHAT = sys.argv[2] if len(sys.argv) > 2 else "primpos"   # or "template"
+IDX = {"primpos": 0, "primrot": 1, "primscale": 2, "template": 3}[WHAT]
 c = T.fuzz_draw(seed, o64)
 a, fs, fe, warp = c["args"], c["fadescale"], c["fadeexp"], c["warp"]
 ref_rgba, ref_sat, st = o64.march_forward(*a, fadescale=fs, fadeexp=fe, ray_diagnostics=True, warp=warp)
@@ -20,16 +22,16 @@ fragile = FragileRays(ref_sat, st["margin"], c["gout"], nsamples=st["nsamples"],
 rgba, grads, diag = T._march(ops, *a, fs, fe, grad_out=fragile, mode="prim", warp=warp)
 g_all = fragile.masked()
 ref = o64.march_backward(*a, ref_sat, g_all, fadescale=fs, fadeexp=fe, warp=warp)
-err = grads["primpos"] - ref[0]
+err = grads[WHAT] - ref[IDX]
 w = np.unravel_index(np.abs(err).argmax(), err.shape)
-print(c["cfg"]); print("worst primpos entry", w, "kernel %.6e oracle %.6e error %.4e (max |g| %.4e)" % (grads["primpos"][w], ref[0][w], err[w], np.abs(ref[0]).max()))
+print(c["cfg"]); print("worst", WHAT, "entry", w, "kernel %.6e oracle %.6e error %.4e (max |g| %.4e)" % (grads[WHAT][w], ref[IDX][w], err[w], np.abs(ref[IDX]).max()))
 n = w[0]
 
 
 def error_of(gout, mode="prim"):
     _, g, _ = T._march(ops, *a, fs, fe, grad_out=gout, mode=mode, warp=warp)
     r = o64.march_backward(*a, ref_sat, gout, fadescale=fs, fadeexp=fe, warp=warp)
-    return g["primpos"][w] - r[0][w], g, r
+    return g[WHAT][w] - r[IDX][w], g, r
 
 
 live = np.argwhere(np.abs(g_all[n]).max(-1) > 0)          # rays of image n with an upstream gradient
@@ -51,10 +53,10 @@ y, x = cand[0]
 g = np.zeros_like(g_all); g[n, y, x] = g_all[n, y, x]
 for mode in ("prim", "ray"):
     e, gk, r = error_of(g, mode)
-    print("ray (%d, %d, %d) alone, %s: primpos[w] kernel %.6e oracle %.6e error %.4e | all primitives: max |error| %.4e at %s" % (
-        n, y, x, mode, gk["primpos"][w], r[0][w], e, np.abs(gk["primpos"] - r[0]).max(),
-        np.unravel_index(np.abs(gk["primpos"] - r[0]).argmax(), r[0].shape)))
+    print("ray (%d, %d, %d) alone, %s: %s[w] kernel %.6e oracle %.6e error %.4e | everywhere: max |error| %.4e at %s" % (
+        n, y, x, mode, WHAT, gk[WHAT][w], r[IDX][w], e, np.abs(gk[WHAT] - r[IDX]).max(),
+        np.unravel_index(np.abs(gk[WHAT] - r[IDX]).argmax(), r[IDX].shape)))
 print("oracle: margin %.3e edge %.3e nsamples %d ref_sat %s rgba %s gout %s" % (st["margin"][n, y, x], st["edge"][n, y, x], st["nsamples"][n, y, x],
                                                                                ref_sat[n, y, x], ref_rgba[n, y, x], g_all[n, y, x]))
 rgba_k, _, _ = T._march(ops, *a, fs, fe, grad_out=None, mode="prim", warp=warp)
-print("kernel rgba", rgba_k[n, y, x])
+print("kernel rgba", rgba_k[n, y, x], "ray o", a[0][n, y, x], "d", a[1][n, y, x], "tminmax", a[3][n, y, x], "dt", a[2])
